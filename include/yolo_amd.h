@@ -1,0 +1,151 @@
+/*
+ * yolo_amd.h -- C ABI of libyolo_amd.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the inference hot path of the luoyang YOLO reference:
+ * conv backbone/neck -> detection head -> decode -> confidence filter + per-class NMS.
+ * The reference is pure Python over ATen/torchvision; each entry point below names the
+ * reference code it replaces (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative YAMD_E* code on failure; the message
+ *     is available from yamd_last_error() (thread local).  Nothing throws across the ABI.
+ *   - all data pointers are DEVICE pointers owned by the caller unless a parameter is
+ *     explicitly called *_host.  The library allocates no device memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only
+ *     enqueue work; they never synchronise.
+ *   - activations are NHWC bf16 with an explicit pixel stride in elements ("cstride"), so a
+ *     tensor may be a channel slice of a wider concat buffer: element (b,y,x,c) lives at
+ *     base[((b*H + y)*W + x)*cstride + c].
+ */
+#ifndef YOLO_AMD_H
+#define YOLO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YAMD_OK 0
+#define YAMD_EINVAL (-1)   /* bad argument / unsupported shape */
+#define YAMD_EHIP (-2)     /* a HIP runtime call failed */
+#define YAMD_ENOSPC (-3)   /* workspace too small */
+
+/* activation fused into the conv epilogue */
+#define YAMD_ACT_NONE 0
+#define YAMD_ACT_SILU 1    /* x*sigmoid(x): yolov5/YoloV5Body.py:16-23, v7/v8 Conv */
+#define YAMD_ACT_LEAKY 2   /* LeakyReLU(0.1): yolov3/DarkNet53.py, v4 neck */
+#define YAMD_ACT_MISH 3    /* x*tanh(softplus(x)): yolov4/YoloV4BackBone.py:10-15 */
+#define YAMD_ACT_RELU 4    /* v6 RepVGG blocks: yolov6_face/YoloV6FaceBody.py:160 */
+
+const char *yamd_last_error(void);
+int yamd_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Conv + folded BatchNorm + activation (+ residual add) as one NHWC implicit-GEMM MFMA kernel.
+ * Replaces nn.Conv2d -> nn.BatchNorm2d -> act of e.g. yolov5/YoloV5Body.py:26-51 (Conv.forward
+ * / forward_fuse), the shortcut add of Bottleneck (:80-93) and the bias-only 1x1 head convs
+ * (:219-221).  groups=1, dilation=1, zero padding k/2; (k,s) in {(1,1),(3,1),(3,2)}.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct yamd_conv_desc {
+    int32_t ksize, stride;
+    int32_t cin;       /* channels of the stored input (multiple of 16; zero-padded weights) */
+    int32_t cout;      /* real output channels */
+    int32_t act;       /* YAMD_ACT_* */
+    int32_t out_f32;   /* 0: y is bf16; 1: y is float (raw head logits) */
+    /* filled by yamd_conv_desc_init (kernel tiling; fixes the packed-weight layout) */
+    int32_t nrep, ck, mrep, cout_pad;
+    int64_t packed_w_elems;   /* bf16 elements of the packed weight blob */
+} yamd_conv_desc;
+
+int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int cin, int cout, int act, int out_f32);
+
+/* Host-side: fold nothing, just reorder.  w_oihw_host is float [cout][cin_real][k][k] (BN already
+ * folded by the caller, cf. utils/torch_utils.py:344-370), bias_host float[cout] or NULL.
+ * Writes packed bf16 weights (d->packed_w_elems uint16) and float bias (d->cout_pad). */
+int yamd_conv_pack_weights(const yamd_conv_desc *d, const float *w_oihw_host, int cin_real,
+                           const float *bias_host, uint16_t *w_packed_host, float *bias_packed_host);
+
+/* y = act(conv(x, w) + bias) (+ residual).  x: (batch,h,w,cin) bf16 NHWC; y: (batch,hout,wout,cout)
+ * with hout = (h + 2*(k/2) - k)/s + 1.  residual may be NULL. */
+int yamd_conv2d_bias_act(const yamd_conv_desc *d, const void *x, int x_cstride, const void *w_packed,
+                         const float *bias_packed, const void *residual, int res_cstride, void *y,
+                         int y_cstride, int batch, int h, int w, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout / resampling helpers of the conv graph.
+ * ---------------------------------------------------------------------------------------- */
+/* Focus space-to-depth + NCHW fp32 -> NHWC bf16 (yolov5/YoloV5Body.py:71-77).  images: (batch,3,h,w)
+ * float NCHW; y: (batch,h/2,w/2,16) bf16, channels [ee RGB, oe RGB, eo RGB, oo RGB, 0,0,0,0] where
+ * the first letter is the row parity (e=even, o=odd) and the second the column parity. */
+int yamd_focus_pack(const float *images, void *y, int y_cstride, int batch, int h, int w, void *stream);
+/* Plain NCHW fp32 -> NHWC bf16 with channels zero-padded to y's 16 (stems without Focus). */
+int yamd_nchw_to_nhwc16(const float *images, void *y, int y_cstride, int batch, int cin, int h, int w,
+                        void *stream);
+/* nn.Upsample(scale_factor=2, mode="nearest") (yolov5/YoloV5Body.py:205) writing into a channel
+ * slice: x (batch,h,w,c) -> y (batch,2h,2w,c). c % 8 == 0. */
+int yamd_upsample2x(const void *x, int x_cstride, void *y, int y_cstride, int batch, int h, int w, int c,
+                    void *stream);
+/* Three cascaded 5x5 stride-1 max-pools with -inf padding: y1 = mp5(x), y2 = mp5(y1), y3 = mp5(y2),
+ * i.e. the k=5,9,13 pools of SPP (yolov5/YoloV5Body.py:114-132, yolov4/YoloV4BackBone.py:151-162)
+ * and the serial pools of SPPF (yolov8/YoloV8Body.py:102-114).  All four tensors are channel slices
+ * (c % 8 == 0) and may live in the same concat buffer. h*w <= 1024. */
+int yamd_maxpool5_cascade(const void *x, int x_cstride, void *y1, void *y2, void *y3, int y_cstride,
+                          int batch, int h, int w, int c, void *stream);
+/* Channel-slice copy (batch*h*w pixels, c channels, c % 8 == 0): torch.cat when a producer could
+ * not write its slice in place. */
+int yamd_copy_channels(const void *x, int x_cstride, void *y, int y_cstride, long long pixels, int c,
+                       void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Head decode.
+ * ---------------------------------------------------------------------------------------- */
+#define YAMD_DECODE_V5 0    /* yolov5/YoloV5Head.py:23-60 (== yolov7/YoloV7Head.py) */
+#define YAMD_DECODE_V3 1    /* yolov3/YoloHead.py:23-65 (v3, v4) */
+#define YAMD_DECODE_POSE 2  /* yolov7_pose/YoloV7PoseHead.py:25-81 (== yolov5_pose) */
+#define YAMD_DECODE_FACE 3  /* yolov7_face/YoloV7FaceHead.py:25-77 (== yolov5_face) */
+
+/* One pyramid level.  raw: (batch,h,w,na*c) float NHWC head logits.  anchors_wh_host: na*2 floats,
+ * anchor sizes in input pixels (host memory, copied into the launch).
+ * merge == 0: writes the head module's output, (batch,na,h,w,c) in grid units, to out.
+ * merge == 1: additionally applies the level merge of yolov5/YoloV5.py:60-69: box (and point) columns
+ *   x stride, rows land at out[b][row_offset + a*h*w + y*w + x][:] of a (batch, rows_per_image, c)
+ *   tensor, cx,cy,w,h clamped to [0, img_size-1]; clamp_points additionally clamps the point
+ *   columns (yolov7_pose/YoloV7Pose.py:156-159, predict only). */
+int yamd_decode_anchor(int kind, const float *raw, int batch, int h, int w, int na, int c,
+                       const float *anchors_wh_host, int stride, int point_num, float img_size, int merge,
+                       int clamp_points, float *out, long long rows_per_image, long long row_offset,
+                       void *stream);
+
+/* Anchor-free DFL decode, one call for all levels (yolov8/YoloV8Head.py:28-60, YoloV8Body.py:204-223,
+ * utils/torch_utils.py:373-394, yolov8/YoloV8.py:48-57 and :118-124).  raw[i]: (batch,h_i,w_i,4*reg_max+nc)
+ * float NHWC, channel order [reg 4*reg_max | cls nc].  out: (batch, sum h_i*w_i, 5+nc) =
+ * [box, max class score, class scores]; box xyxy (out_cxcywh=0) or cxcywh (1), input pixels. */
+int yamd_decode_dfl(const float *const *raw_host_ptrs, const int *hs_host, const int *ws_host,
+                    const int *strides_host, int n_levels, int batch, int reg_max, int nc, int out_cxcywh,
+                    float *out, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Confidence filter + per-class greedy NMS for a whole batch; replaces the Python per-image loop
+ * of utils/torch_utils.py:101-141 (n_extra = 0), :144-191 (n_extra = 2P) and :194-241 (n_extra = 3P)
+ * including its torchvision.ops.box_convert / torchvision.ops.nms calls.
+ *   pred      (batch, a, c) float: [b0,b1,b2,b3,obj, n_extra columns, class scores...]
+ *   out_rows  (batch, max_out, 7+n_extra) float: [x1,y1,x2,y2,obj,cls_conf, extra..., cls_id], rows
+ *             in descending score order (ties: ascending anchor index) exactly as the reference
+ *             returns them
+ *   out_index (batch, max_out) int32 source anchor index of every kept row, or NULL
+ *   out_counts (batch) int32 kept rows per image (0 <=> the reference returns None); rows beyond
+ *             max_out are dropped but still counted
+ * The IoU test is bit-exact with the torchvision CPU kernel: fp32 arithmetic on the class-offset
+ * boxes (offset = cls*4096 added in fp32), strict '>', compared against the double threshold.
+ * ---------------------------------------------------------------------------------------- */
+size_t yamd_nms_workspace_bytes(int batch, int a, int c, int n_extra);
+int yamd_nms_batched(const float *pred, int batch, int a, int c, int in_cxcywh, int n_extra, float img_size,
+                     float conf_thr, double iou_thr, float *out_rows, int *out_index, int max_out,
+                     int *out_counts, void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO_AMD_H */

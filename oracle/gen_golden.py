@@ -1,0 +1,291 @@
+"""TEST INFRASTRUCTURE ONLY -- regenerates tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference):  python -m oracle.gen_golden
+The reference publishes no tests or fixtures, so every golden vector here is an output of the
+reference's own code (luoyang/...) on seeded inputs; torchvision.ops is replaced by the stand-in of
+oracle/ref_harness.py (torchvision is not installed, see there).  Fixtures are data only: seeds,
+input tensors and the reference's outputs.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_harness  # noqa: E402
+
+ref_harness.install()
+
+from luoyang.param.Param import Yolo3Param, Yolo5Param, Yolo7FaceParam, Yolo7PoseParam, Yolo8Param  # noqa: E402
+from luoyang.utils import torch_utils as ref_tu  # noqa: E402
+from luoyang.yolov3.YoloHead import YoloHead  # noqa: E402
+from luoyang.yolov3.YoloV3 import YoloV3  # noqa: E402
+from luoyang.yolov5.YoloV5 import YoloV5  # noqa: E402
+from luoyang.yolov5.YoloV5Head import YoloV5Head  # noqa: E402
+from luoyang.yolov7_face.YoloV7FaceHead import YoloV7FaceHead  # noqa: E402
+from luoyang.yolov7_pose.YoloV7Pose import YoloV7Pose  # noqa: E402
+from luoyang.yolov7_pose.YoloV7PoseHead import YoloV7PoseHead  # noqa: E402
+from luoyang.yolov8.YoloV8 import YoloV8  # noqa: E402
+from luoyang.yolov8.YoloV8Head import YoloV8Head  # noqa: E402
+
+from yolo_amd.init import seeded_images, seeded_state_dict  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _rows(lst, width):
+    """List[Optional[Tensor(K,W)]] -> (counts, concatenated rows)."""
+    counts = np.array([0 if r is None else int(r.shape[0]) for r in lst], dtype=np.int64)
+    rows = [np.asarray(r, dtype=np.float32).reshape(-1, width) for r in lst if r is not None]
+    return counts, (np.concatenate(rows, 0) if rows else np.zeros((0, width), np.float32))
+
+
+def _np(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_v5s():
+    """YOLOv5s end to end at 64x64 (B=2) and 640x640 (B=1, subsampled rows)."""
+    torch.set_num_threads(8)
+    for size, batch, seed in ((64, 2, 11), (640, 1, 12)):
+        p = Yolo5Param(m_type="s")
+        p.img_size = size
+        p.feature_size = [size // 8, size // 16, size // 32]
+        p.darknet_csp_weight_path = None
+        model = YoloV5(p).eval()
+        sd = seeded_state_dict(model, seed=seed, mode="spread")
+        model.load_state_dict(sd, strict=True)
+        imgs = torch.from_numpy(seeded_images(batch, size, seed=seed))
+        with torch.no_grad():
+            out5, out4, out3 = model.body_net(imgs)
+            pred = model._forward(imgs)[0]
+            td = model.forward({"batch_images": imgs})
+            res = model.predict({"batch_images": imgs})["predicts"]
+        counts, rows = _rows(res, 7)
+        d = dict(seed=seed, size=size, batch=batch, counts=counts, rows=rows,
+                 conf_threshold=p.conf_threshold, nms_threshold=p.nms_threshold)
+        if size == 64:
+            d.update(raw_p3=_np(out3), raw_p4=_np(out4), raw_p5=_np(out5), pred=_np(pred),
+                     head3=_np(td["head3_predicts"]), head4=_np(td["head4_predicts"]), head5=_np(td["head5_predicts"]))
+        else:
+            sel = np.arange(0, pred.shape[1], 37)
+            d.update(pred_rows=sel, pred=_np(pred)[:, sel], raw_p5=_np(out5))
+        np.savez_compressed(os.path.join(GOLD, f"v5s_{size}.npz"), **d)
+        print("v5s", size, "kept", counts.tolist())
+        if size == 64:
+            # fused checkpoint of the same model: state_dict keys/values after the reference's fuse()
+            model.fuse()
+            fs = model.state_dict()
+            keys = ["body_net.backbone.stem.conv.conv.weight", "body_net.backbone.stem.conv.conv.bias",
+                    "body_net.conv3_for_up_sample1.m.0.cv2.conv.weight", "body_net.conv3_for_up_sample1.m.0.cv2.conv.bias"]
+            with torch.no_grad():
+                pred_f = model._forward(imgs)[0]
+            np.savez_compressed(os.path.join(GOLD, "v5s_64_fused.npz"), n_keys=len(fs), pred=_np(pred_f),
+                                **{k.replace(".", "__"): _np(fs[k])[:8] for k in keys})
+
+
+# ------------------------------------------------------------------------------------------------
+def _stub(cls, param, heads, out_size, body):
+    m = cls.__new__(cls)
+    nn.Module.__init__(m)
+    m.param = param
+    m.body_output_size = out_size
+    m.yolo_head3, m.yolo_head4, m.yolo_head5 = heads
+    m.body_net = body
+    return m
+
+
+def gen_decode():
+    """Head decode + level merge of every head kind on N(0,2) logits, feature sizes 8/4/2 (img 64)."""
+    rng = np.random.RandomState(5)
+    size, fs, B = 64, [8, 4, 2], 2
+    out = {}
+
+    def raws(C):
+        r = [torch.from_numpy((rng.standard_normal((B, 3 * C, f, f)) * 2.0).astype(np.float32)) for f in fs]
+        return r   # [P3, P4, P5]
+
+    # v5
+    p = Yolo5Param(m_type="s"); p.img_size = size; p.feature_size = fs
+    C = 25
+    heads = [YoloV5Head(stride=s, yolo_output_size=C, input_size=(f, f), anchors=p.anchors[3 * i:3 * i + 3])
+             for i, (s, f) in enumerate(zip(p.strides, fs))]
+    r = raws(C)
+    m = _stub(YoloV5, p, heads, C, lambda images: (r[2].clone(), r[1].clone(), r[0].clone()))
+    with torch.no_grad():
+        out["v5_pred"] = _np(m._forward(None)[0])
+        out["v5_head3"] = _np(heads[0](r[0].clone()))
+    for i in range(3):
+        out[f"v5_raw{i}"] = _np(r[i])
+    # v3
+    p3 = Yolo3Param(); p3.img_size = size; p3.feature_size = fs
+    heads = [YoloHead(stride=s, yolo_output_size=C, input_size=(f, f), anchors=p3.anchors[3 * i:3 * i + 3])
+             for i, (s, f) in enumerate(zip(p3.strides, fs))]
+    r3 = raws(C)
+    m = _stub(YoloV3, p3, heads, C, lambda images: (r3[2].clone(), r3[1].clone(), r3[0].clone()))
+    with torch.no_grad():
+        out["v3_pred"] = _np(m._forward(None)[0])
+    for i in range(3):
+        out[f"v3_raw{i}"] = _np(r3[i])
+    # pose (17 points, 1 class): _forward (no point clamp) and predict's merged tensor (points clamped)
+    pp = Yolo7PoseParam(m_type="l"); pp.img_size = size; pp.feature_size = fs
+    Cp = 5 + 3 * 17 + 1
+    heads = [YoloV7PoseHead(stride=s, point_num=17, yolo_output_size=Cp, input_size=(f, f),
+                            anchors=pp.anchors[3 * i:3 * i + 3]) for i, (s, f) in enumerate(zip(pp.strides, fs))]
+    rp = raws(Cp)
+    m = _stub(YoloV7Pose, pp, heads, Cp, lambda images: (rp[2].clone(), rp[1].clone(), rp[0].clone()))
+    with torch.no_grad():
+        out["pose_pred"] = _np(m._forward(None)[0])
+        res = m.predict({"batch_images": None})["predicts"]
+    out["pose_counts"], out["pose_rows"] = _rows(res, 6 + 3 * 17 + 1)
+    out["pose_conf"], out["pose_nms"] = pp.conf_threshold, pp.nms_threshold
+    for i in range(3):
+        out[f"pose_raw{i}"] = _np(rp[i])
+    # face (5 points, 1 class): head modules + the merge of the face models (same as pose: box and points x stride)
+    pf = Yolo7FaceParam(m_type="l"); pf.img_size = size; pf.feature_size = fs
+    Cf = 5 + 2 * 5 + 1
+    heads = [YoloV7FaceHead(stride=s, point_num=5, yolo_output_size=Cf, input_size=(f, f),
+                            anchors=pf.anchors[3 * i:3 * i + 3]) for i, (s, f) in enumerate(zip(pf.strides, fs))]
+    rf = raws(Cf)
+    with torch.no_grad():
+        lv = [h(x.clone()) for h, x in zip(heads, rf)]
+    for i in range(3):
+        out[f"face_raw{i}"] = _np(rf[i])
+        out[f"face_head{i}"] = _np(lv[i])
+    # v8 DFL: _forward (cxcywh) and predict (xyxy + NMS)
+    p8 = Yolo8Param(m_type="s"); p8.img_size = size; p8.feature_size = fs
+    nc = 20
+    m8 = YoloV8.__new__(YoloV8)
+    nn.Module.__init__(m8)
+    m8.param = p8
+    m8.head = YoloV8Head(reg_max=16, stride=p8.strides, feature_size=fs, num_classes=nc, use_dfl=True)
+    r8 = [torch.from_numpy((rng.standard_normal((B, 64 + nc, f, f)) * 2.0).astype(np.float32)) for f in fs]
+    m8.body_net = lambda images: [x.clone() for x in r8]
+    with torch.no_grad():
+        out["v8_pred_cxcywh"] = _np(m8._forward(None)[0])
+        td = m8._feed_forward({"batch_images": None})
+        boxes = td["predict_scaled_bounding_boxes"] * td["stride_tensor"]
+        conf, _ = torch.max(td["predict_scores"], dim=-1, keepdim=True)
+        out["v8_pred_xyxy"] = _np(torch.cat([boxes, conf, td["predict_scores"]], dim=-1))
+        res = m8.predict({"batch_images": None})["predicts"]
+    out["v8_counts"], out["v8_rows"] = _rows(res, 7)
+    for i in range(3):
+        out[f"v8_raw{i}"] = _np(r8[i])
+    np.savez_compressed(os.path.join(GOLD, "decode.npz"), **out)
+    print("decode goldens:", {k: v.shape for k, v in out.items() if hasattr(v, "shape") and "pred" in k})
+
+
+# ------------------------------------------------------------------------------------------------
+def _synthetic_pred(rng, B, A, nc, img, n_extra=0, clusters=12, fmt="cxcywh", obj_bias=0.0):
+    """Clustered boxes with realistic overlaps: (B, A, 5+n_extra+nc)."""
+    cen = rng.uniform(0.1 * img, 0.9 * img, (B, clusters, 2))
+    siz = rng.uniform(0.05 * img, 0.4 * img, (B, clusters, 2))
+    which = rng.randint(0, clusters, (B, A))
+    bi = np.arange(B)[:, None]
+    cxy = cen[bi, which] + rng.standard_normal((B, A, 2)) * 0.03 * img
+    wh = siz[bi, which] * np.exp(rng.standard_normal((B, A, 2)) * 0.15)
+    obj = 1.0 / (1.0 + np.exp(-(rng.standard_normal((B, A, 1)) * 2.0 + obj_bias)))
+    cls_logit = rng.standard_normal((B, A, nc)) * 2.0
+    fav = rng.randint(0, nc, (B, clusters))[bi, which]
+    cls_logit[bi, np.arange(A)[None, :], fav] += 3.0
+    cls = 1.0 / (1.0 + np.exp(-cls_logit))
+    if fmt == "xyxy":
+        box = np.concatenate((cxy - wh / 2, cxy + wh / 2), -1)
+    else:
+        box = np.concatenate((cxy, wh), -1)
+    extra = rng.uniform(-0.1 * img, 1.1 * img, (B, A, n_extra))
+    return np.concatenate((box, obj, extra, cls), -1).astype(np.float32)
+
+
+def gen_nms():
+    rng = np.random.RandomState(7)
+    out = {}
+    cases = []
+
+    def run(name, pred, img, fmt="cxcywh", conf=0.1, nms=0.3, P=0, point_conf=False):
+        t = torch.from_numpy(pred)
+        if P == 0:
+            res = ref_tu.non_max_suppression(t, img_size=img, in_fmt=fmt, conf_threshold=conf, nms_threshold=nms)
+            width = 7
+        elif not point_conf:
+            res = ref_tu.non_max_suppression_with_point(t, img_size=img, point_num=P, in_fmt=fmt,
+                                                        conf_threshold=conf, nms_threshold=nms)
+            width = 6 + 2 * P + 1
+        else:
+            res = ref_tu.non_max_suppression_with_point_conf(t, img_size=img, point_num=P, in_fmt=fmt,
+                                                             conf_threshold=conf, nms_threshold=nms)
+            width = 6 + 3 * P + 1
+        counts, rows = _rows(res, width)
+        out[f"{name}__pred"] = pred
+        out[f"{name}__counts"] = counts
+        out[f"{name}__rows"] = rows
+        out[f"{name}__meta"] = np.array([img, 1.0 if fmt == "cxcywh" else 0.0, conf, nms, P, 1.0 if point_conf else 0.0],
+                                        dtype=np.float64)
+        cases.append(name)
+        print("nms case", name, pred.shape, "kept", counts.tolist())
+
+    # clustered, 20 classes (class ids up to 19 -> offsets up to 77824: coordinates quantised to 2^-7)
+    run("clustered20", _synthetic_pred(rng, 3, 300, 20, 640.0), 640.0)
+    # single class, xyxy input, higher thresholds
+    run("single_xyxy", _synthetic_pred(rng, 2, 200, 1, 416.0, fmt="xyxy"), 416.0, fmt="xyxy", conf=0.3, nms=0.5)
+    # the all-pass regime of a default-initialised detector: grid of anchor-sized boxes, near-equal scores
+    g = 16
+    ys, xs = np.meshgrid(np.arange(g), np.arange(g), indexing="ij")
+    boxes = []
+    for (aw, ah) in ((10, 13), (16, 30), (33, 23)):
+        boxes.append(np.stack((xs.ravel() * 8 + 4.0, ys.ravel() * 8 + 4.0, np.full(g * g, aw), np.full(g * g, ah)), -1))
+    box = np.concatenate(boxes, 0)[None]
+    A = box.shape[1]
+    obj = np.full((1, A, 1), 0.5) + rng.uniform(-1e-3, 1e-3, (1, A, 1))
+    cls = np.full((1, A, 20), 0.5) + rng.uniform(-1e-3, 1e-3, (1, A, 20))
+    run("allpass_grid", np.concatenate((box, obj, cls), -1).astype(np.float32), 128.0)
+    # exact score ties (stable order decides) incl. duplicated boxes
+    pt = _synthetic_pred(rng, 1, 96, 3, 320.0)
+    pt[0, :, 4] = 0.5
+    pt[0, :, 5:] = np.where(pt[0, :, 5:] > 0.5, 0.75, 0.25)
+    pt[0, 48:] = pt[0, :48]
+    run("ties", pt, 320.0)
+    # IoU exactly at the threshold: (0,0,4,4)&(0,0,4,2) -> 0.5 with thr 0.5 (strict '>' keeps both);
+    # (0,0,2,2)&(1,0,3,2) -> float 1/3 compared with double 1/3 (float is larger -> suppressed)
+    def two(b1, b2, s1=0.9, s2=0.8):
+        p = np.zeros((1, 2, 6), np.float32)
+        p[0, 0, :4], p[0, 1, :4] = b1, b2
+        p[0, :, 4] = (s1, s2)
+        p[0, :, 5] = 1.0
+        return p
+    run("iou_eq_half", two((0, 0, 4, 4), (0, 0, 4, 2)), 64.0, fmt="xyxy", conf=0.1, nms=0.5)
+    run("iou_third", two((0, 0, 2, 2), (1, 0, 3, 2)), 64.0, fmt="xyxy", conf=0.1, nms=1.0 / 3.0)
+    # zero-area boxes (0/0 = NaN never suppresses) + identical boxes + boxes clamped at the border
+    pz = np.zeros((1, 8, 7), np.float32)
+    pz[0, :, :4] = [(5, 5, 5, 5), (5, 5, 5, 5), (5, 5, 9, 5), (10, 10, 20, 20), (10, 10, 20, 20), (-30, -30, 8, 8),
+                    (60, 60, 90, 90), (63, 63, 200, 200)]
+    pz[0, :, 4] = np.linspace(0.9, 0.5, 8)
+    pz[0, :, 5] = 0.9
+    pz[0, :, 6] = 0.1
+    run("degenerate", pz, 64.0, fmt="xyxy", conf=0.1, nms=0.3)
+    # images without any candidate -> None
+    pn = _synthetic_pred(rng, 3, 64, 4, 320.0)
+    pn[0, :, 4] = 1e-3
+    pn[2, :, 4] = 1e-3
+    run("none_images", pn, 320.0, conf=0.25)
+    # landmark / keypoint variants
+    run("face5", _synthetic_pred(rng, 2, 150, 1, 640.0, n_extra=10), 640.0, conf=0.3, P=5)
+    run("pose17", _synthetic_pred(rng, 2, 150, 1, 640.0, n_extra=51), 640.0, conf=0.3, P=17, point_conf=True)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(GOLD, "nms.npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["nms", "decode", "v5s"]
+    if "nms" in which:
+        gen_nms()
+    if "decode" in which:
+        gen_decode()
+    if "v5s" in which:
+        gen_v5s()

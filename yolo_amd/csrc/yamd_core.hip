@@ -1,0 +1,229 @@
+// Error channel + layout / resampling kernels of the conv graph (all HBM-bound, 16-byte accesses).
+#include "yamd_common.h"
+
+#include <cstring>
+
+namespace yamd {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace yamd
+
+using namespace yamd;
+
+extern "C" const char *yamd_last_error(void) { return g_err; }
+extern "C" int yamd_version(void) { return 100; }
+
+namespace {
+
+// one thread per output pixel: 2x2 input patch of 3 planes -> 16 bf16 channels (32 bytes)
+__global__ void focus_pack_kernel(const float *__restrict__ img, __bf16 *__restrict__ y, int y_cs, int B, int H, int W)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)B * Ho * Wo;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo);
+        const int oy = (int)((i / Wo) % Ho);
+        const int b = (int)(i / ((long long)Wo * Ho));
+        float v[2][2][3];   // [row parity][col parity][channel]
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float2 t = *(const float2 *)(img + (((long long)b * 3 + c) * H + (2 * oy + r)) * W + 2 * ox);
+                v[r][0][c] = t.x;
+                v[r][1][c] = t.y;
+            }
+        bf16x8 lo, hi;
+        // channel order: (even row, even col), (odd row, even col), (even row, odd col), (odd, odd)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = (__bf16)v[0][0][c];
+            lo[3 + c] = (__bf16)v[1][0][c];
+        }
+        lo[6] = (__bf16)v[0][1][0];
+        lo[7] = (__bf16)v[0][1][1];
+        hi[0] = (__bf16)v[0][1][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) hi[1 + c] = (__bf16)v[1][1][c];
+        hi[4] = hi[5] = hi[6] = hi[7] = (__bf16)0.0f;
+        __bf16 *dst = y + i * y_cs;
+        *(bf16x8 *)dst = lo;
+        *(bf16x8 *)(dst + 8) = hi;
+    }
+}
+
+__global__ void nchw_to_nhwc16_kernel(const float *__restrict__ img, __bf16 *__restrict__ y, int y_cs, int B, int C, int H,
+                                      int W)
+{
+    const long long hw = (long long)H * W, total = (long long)B * hw;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / hw, s = i % hw;
+        bf16x8 lo, hi;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) lo[c] = (__bf16)(c < C ? img[(b * C + c) * hw + s] : 0.0f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) hi[c] = (__bf16)(8 + c < C ? img[(b * C + 8 + c) * hw + s] : 0.0f);
+        __bf16 *dst = y + i * y_cs;
+        *(bf16x8 *)dst = lo;
+        *(bf16x8 *)(dst + 8) = hi;
+    }
+}
+
+// one thread per (output pixel, 8-channel piece)
+__global__ void upsample2x_kernel(const __bf16 *__restrict__ x, int x_cs, __bf16 *__restrict__ y, int y_cs, int B, int H,
+                                  int W, int C8)
+{
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long total = (long long)B * Ho * Wo * C8;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        const long long pix = i / C8;
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const long long b = pix / ((long long)Wo * Ho);
+        const uint4 v = *(const uint4 *)(x + ((b * H + (oy >> 1)) * W + (ox >> 1)) * x_cs + c8 * 8);
+        *(uint4 *)(y + pix * y_cs + c8 * 8) = v;
+    }
+}
+
+__global__ void copy_channels_kernel(const __bf16 *__restrict__ x, int x_cs, __bf16 *__restrict__ y, int y_cs,
+                                     long long pixels, int C8)
+{
+    const long long total = pixels * C8;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        const long long pix = i / C8;
+        *(uint4 *)(y + pix * y_cs + c8 * 8) = *(const uint4 *)(x + pix * x_cs + c8 * 8);
+    }
+}
+
+__device__ __forceinline__ bf16x8 max8(bf16x8 a, bf16x8 b)
+{
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = ((float)a[i] > (float)b[i]) ? a[i] : b[i];
+    return r;
+}
+
+// One workgroup per (image, 8-channel piece): the whole h*w plane of 16-byte pixels sits in LDS;
+// a 5x5 max is a 5-tap row pass followed by a 5-tap column pass, applied three times.
+__global__ void maxpool5_cascade_kernel(const __bf16 *__restrict__ x, int x_cs, __bf16 *__restrict__ y1,
+                                        __bf16 *__restrict__ y2, __bf16 *__restrict__ y3, int y_cs, int H, int W, int C8)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16x8 *cur = (bf16x8 *)smem;
+    bf16x8 *tmp = cur + H * W;
+    const int c8 = blockIdx.x % C8;
+    const long long b = blockIdx.x / C8;
+    const int n = H * W;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        cur[i] = *(const bf16x8 *)(x + (b * n + i) * x_cs + c8 * 8);
+    __syncthreads();
+    __bf16 *outs[3] = {y1, y2, y3};
+    for (int pass = 0; pass < 3; ++pass) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int r = i / W, c = i % W;
+            bf16x8 m = cur[i];
+            for (int d = -2; d <= 2; ++d) {
+                const int cc = c + d;
+                if (d != 0 && cc >= 0 && cc < W) m = max8(m, cur[r * W + cc]);
+            }
+            tmp[i] = m;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int r = i / W, c = i % W;
+            bf16x8 m = tmp[i];
+            for (int d = -2; d <= 2; ++d) {
+                const int rr = r + d;
+                if (d != 0 && rr >= 0 && rr < H) m = max8(m, tmp[rr * W + c]);
+            }
+            *(bf16x8 *)(outs[pass] + (b * n + i) * y_cs + c8 * 8) = m;
+            // the column pass reads tmp only, so cur can be overwritten for the next pass
+            cur[i] = m;
+        }
+        __syncthreads();
+    }
+}
+
+int grid_for(long long total, int block) { long long g = (total + block - 1) / block; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
+
+}  // namespace
+
+extern "C" int yamd_focus_pack(const float *images, void *y, int y_cstride, int batch, int h, int w, void *stream)
+{
+    YAMD_REQUIRE(images && y, "null argument");
+    YAMD_REQUIRE(batch > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, "focus needs even h,w (got %dx%d)", h, w);
+    YAMD_REQUIRE(y_cstride >= 16 && y_cstride % 8 == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)images % 8) == 0,
+                 "focus output needs 16-byte aligned pixels");
+    const long long total = (long long)batch * (h / 2) * (w / 2);
+    hipLaunchKernelGGL(focus_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, images,
+                       (__bf16 *)y, y_cstride, batch, h, w);
+    YAMD_LAUNCH_CHECK();
+    return YAMD_OK;
+}
+
+extern "C" int yamd_nchw_to_nhwc16(const float *images, void *y, int y_cstride, int batch, int cin, int h, int w,
+                                   void *stream)
+{
+    YAMD_REQUIRE(images && y, "null argument");
+    YAMD_REQUIRE(batch > 0 && h > 0 && w > 0 && cin > 0 && cin <= 16, "bad shape");
+    YAMD_REQUIRE(y_cstride >= 16 && y_cstride % 8 == 0 && ((uintptr_t)y % 16) == 0, "output needs 16-byte aligned pixels");
+    const long long total = (long long)batch * h * w;
+    hipLaunchKernelGGL(nchw_to_nhwc16_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, images,
+                       (__bf16 *)y, y_cstride, batch, cin, h, w);
+    YAMD_LAUNCH_CHECK();
+    return YAMD_OK;
+}
+
+extern "C" int yamd_upsample2x(const void *x, int x_cstride, void *y, int y_cstride, int batch, int h, int w, int c,
+                               void *stream)
+{
+    YAMD_REQUIRE(x && y, "null argument");
+    YAMD_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "bad shape (c=%d must be a multiple of 8)", c);
+    YAMD_REQUIRE(x_cstride % 8 == 0 && y_cstride % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0,
+                 "upsample needs 16-byte aligned pixels");
+    const long long total = (long long)batch * 4 * h * w * (c / 8);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16 *)x, x_cstride, (__bf16 *)y, y_cstride, batch, h, w, c / 8);
+    YAMD_LAUNCH_CHECK();
+    return YAMD_OK;
+}
+
+extern "C" int yamd_copy_channels(const void *x, int x_cstride, void *y, int y_cstride, long long pixels, int c,
+                                  void *stream)
+{
+    YAMD_REQUIRE(x && y, "null argument");
+    YAMD_REQUIRE(pixels > 0 && c > 0 && c % 8 == 0, "bad shape");
+    YAMD_REQUIRE(x_cstride % 8 == 0 && y_cstride % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0,
+                 "copy needs 16-byte aligned pixels");
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(pixels * (c / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16 *)x, x_cstride, (__bf16 *)y, y_cstride, pixels, c / 8);
+    YAMD_LAUNCH_CHECK();
+    return YAMD_OK;
+}
+
+extern "C" int yamd_maxpool5_cascade(const void *x, int x_cstride, void *y1, void *y2, void *y3, int y_cstride, int batch,
+                                     int h, int w, int c, void *stream)
+{
+    YAMD_REQUIRE(x && y1 && y2 && y3, "null argument");
+    YAMD_REQUIRE(batch > 0 && h > 0 && w > 0 && h * w <= 1024 && c > 0 && c % 8 == 0, "maxpool: bad shape %dx%dx%d", h, w, c);
+    YAMD_REQUIRE(x_cstride % 8 == 0 && y_cstride % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y1 % 16) == 0 &&
+                     ((uintptr_t)y2 % 16) == 0 && ((uintptr_t)y3 % 16) == 0,
+                 "maxpool needs 16-byte aligned pixels");
+    const size_t lds = (size_t)h * w * 16 * 2;
+    hipLaunchKernelGGL(maxpool5_cascade_kernel, dim3(batch * (c / 8)), dim3(256), lds, (hipStream_t)stream,
+                       (const __bf16 *)x, x_cstride, (__bf16 *)y1, (__bf16 *)y2, (__bf16 *)y3, y_cstride, h, w, c / 8);
+    YAMD_LAUNCH_CHECK();
+    return YAMD_OK;
+}

@@ -1,0 +1,246 @@
+// Head decode kernels (HBM-bound).  Build with -ffp-contract=off: the arithmetic follows the
+// reference's fp32 operation order one rounding at a time.
+//
+// Anchor heads: a workgroup takes PIX consecutive pixels of one image, copies their raw logits
+// (PIX x na*C floats, contiguous in NHWC) into LDS with coalesced loads, and writes one contiguous
+// run of PIX rows x C floats per anchor (rows of one anchor are consecutive in the output), so both
+// sides of the kernel stream whole cache lines.
+#include "yamd_common.h"
+
+using namespace yamd;
+
+namespace {
+
+constexpr int PIX = 64;
+
+struct AnchorDecodeParams {
+    const float *raw;
+    float *out;
+    int H, W, na, C, kind, P, stride, merge, clamp_points;
+    float hi;                 // img_size - 1
+    float aw[8], ah[8];       // anchor / stride, fp32 division as torch does it
+    long long rows_per_image, row_offset;
+};
+
+__device__ __forceinline__ float sigmoidf_exact(float t) { return 1.0f / (1.0f + expf(-t)); }
+
+__global__ __launch_bounds__(256) void decode_anchor_kernel(AnchorDecodeParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float sraw[];
+    const int HW = p.H * p.W;
+    const int naC = p.na * p.C;
+    const int p0 = blockIdx.x * PIX;
+    const int np = min(PIX, HW - p0);
+    const long long b = blockIdx.y;
+    const float *src = p.raw + (b * HW + p0) * (long long)naC;
+    const int total = np * naC;
+    if (((uintptr_t)src & 15) == 0) {
+        const int t4 = total >> 2;
+        for (int i = threadIdx.x; i < t4; i += 256) ((float4 *)sraw)[i] = ((const float4 *)src)[i];
+        for (int i = (t4 << 2) + threadIdx.x; i < total; i += 256) sraw[i] = src[i];
+    } else {
+        for (int i = threadIdx.x; i < total; i += 256) sraw[i] = src[i];
+    }
+    __syncthreads();
+
+    const int cl = threadIdx.x & 31;    // column lane
+    const int rl = threadIdx.x >> 5;    // 8 rows in flight
+    const float fs = (float)p.stride;
+    for (int r = rl; r < p.na * PIX; r += 8) {
+        const int a = r / PIX, pix = r % PIX;
+        if (pix >= np) continue;
+        const int gp = p0 + pix;
+        const float gx = (float)(gp % p.W), gy = (float)(gp / p.W);
+        const float aw = p.aw[a], ah = p.ah[a];
+        const float *row = sraw + pix * naC + a * p.C;
+        float *dst = p.out + ((b * p.rows_per_image + p.row_offset + (long long)a * HW + gp) * p.C);
+        for (int c = cl; c < p.C; c += 32) {
+            const float t = row[c];
+            float v;
+            bool is_box = c < 4, is_pt = false;
+            if (p.kind == YAMD_DECODE_V3) {
+                if (c == 0) v = sigmoidf_exact(t) + gx;
+                else if (c == 1) v = sigmoidf_exact(t) + gy;
+                else if (c == 2) v = expf(t) * aw;
+                else if (c == 3) v = expf(t) * ah;
+                else v = sigmoidf_exact(t);
+            } else {
+                const int pe = 5 + 2 * p.P;
+                if (c >= 5 && c < pe && p.kind != YAMD_DECODE_V5) {
+                    is_pt = true;
+                    const bool isx = ((c - 5) & 1) == 0;
+                    if (p.kind == YAMD_DECODE_POSE) v = (2.0f * t - 0.5f) + (isx ? gx : gy);
+                    else v = t * (isx ? aw : ah) + (isx ? gx : gy);
+                } else {
+                    const float s = sigmoidf_exact(t);
+                    if (c == 0) v = 2.0f * s - 0.5f + gx;
+                    else if (c == 1) v = 2.0f * s - 0.5f + gy;
+                    else if (c == 2) { const float w2 = 2.0f * s; v = (w2 * w2) * aw; }
+                    else if (c == 3) { const float h2 = 2.0f * s; v = (h2 * h2) * ah; }
+                    else v = s;
+                }
+            }
+            if (p.merge) {
+                if (is_box) {
+                    v = v * fs;
+                    v = fminf(fmaxf(v, 0.0f), p.hi);
+                } else if (is_pt) {
+                    v = v * fs;
+                    if (p.clamp_points) v = fminf(fmaxf(v, 0.0f), p.hi);
+                }
+            }
+            dst[c] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// DFL: one workgroup per DPIX pixels of one level.
+constexpr int DPIX = 32;
+
+struct DflParams {
+    const float *raw;
+    float *out;
+    int H, W, reg_max, nc, stride, out_cxcywh;
+    long long rows_per_image, row_offset;
+};
+
+__global__ __launch_bounds__(256) void decode_dfl_kernel(DflParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int HW = p.H * p.W;
+    const int CI = 4 * p.reg_max + p.nc;   // input channels per pixel
+    const int CO = 5 + p.nc;               // output columns
+    float *sraw = sm;                      // DPIX * CI
+    float *sout = sm + DPIX * CI;          // DPIX * CO
+    const int p0 = blockIdx.x * DPIX;
+    const int np = min(DPIX, HW - p0);
+    const long long b = blockIdx.y;
+    const float *src = p.raw + (b * HW + p0) * (long long)CI;
+    const int total = np * CI;
+    if (((uintptr_t)src & 15) == 0) {
+        const int t4 = total >> 2;
+        for (int i = threadIdx.x; i < t4; i += 256) ((float4 *)sraw)[i] = ((const float4 *)src)[i];
+        for (int i = (t4 << 2) + threadIdx.x; i < total; i += 256) sraw[i] = src[i];
+    } else {
+        for (int i = threadIdx.x; i < total; i += 256) sraw[i] = src[i];
+    }
+    __syncthreads();
+    // box sides: thread -> (pixel, side)
+    if (threadIdx.x < 4 * DPIX) {
+        const int pix = threadIdx.x >> 2, side = threadIdx.x & 3;
+        if (pix < np) {
+            const float *d = sraw + pix * CI + side * p.reg_max;
+            float mx = d[0];
+            for (int i = 1; i < p.reg_max; ++i) mx = fmaxf(mx, d[i]);
+            float sum = 0.0f;
+            for (int i = 0; i < p.reg_max; ++i) sum += expf(d[i] - mx);
+            float e = 0.0f;
+            for (int i = 0; i < p.reg_max; ++i) e += (expf(d[i] - mx) / sum) * (float)i;
+            sout[pix * CO + side] = e;   // ltrb distance in grid units
+        }
+    }
+    // class scores
+    for (int i = threadIdx.x; i < np * p.nc; i += 256) {
+        const int pix = i / p.nc, c = i % p.nc;
+        sout[pix * CO + 5 + c] = 1.0f / (1.0f + expf(-sraw[pix * CI + 4 * p.reg_max + c]));
+    }
+    __syncthreads();
+    if (threadIdx.x < np) {
+        const int pix = threadIdx.x, gp = p0 + pix;
+        float *o = sout + pix * CO;
+        const float ax = (float)(gp % p.W) + 0.5f, ay = (float)(gp / p.W) + 0.5f;
+        const float fs = (float)p.stride;
+        const float x1 = (ax - o[0]) * fs, y1 = (ay - o[1]) * fs, x2 = (ax + o[2]) * fs, y2 = (ay + o[3]) * fs;
+        if (p.out_cxcywh) {
+            o[0] = (x1 + x2) / 2.0f;
+            o[1] = (y1 + y2) / 2.0f;
+            o[2] = x2 - x1;
+            o[3] = y2 - y1;
+        } else {
+            o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
+        }
+        float best = o[5];
+        for (int c = 1; c < p.nc; ++c) best = fmaxf(best, o[5 + c]);
+        o[4] = best;
+    }
+    __syncthreads();
+    float *dst = p.out + (b * p.rows_per_image + p.row_offset + p0) * (long long)CO;
+    for (int i = threadIdx.x; i < np * CO; i += 256) dst[i] = sout[i];
+}
+
+}  // namespace
+
+extern "C" int yamd_decode_anchor(int kind, const float *raw, int batch, int h, int w, int na, int c,
+                                  const float *anchors_wh_host, int stride, int point_num, float img_size, int merge,
+                                  int clamp_points, float *out, long long rows_per_image, long long row_offset,
+                                  void *stream)
+{
+    YAMD_REQUIRE(raw && out && anchors_wh_host, "null argument");
+    YAMD_REQUIRE(kind >= YAMD_DECODE_V5 && kind <= YAMD_DECODE_FACE, "unknown decode kind %d", kind);
+    YAMD_REQUIRE(batch > 0 && batch <= 65535 && h > 0 && w > 0 && na > 0 && na <= 8 && stride > 0, "bad shape");
+    const int need = (kind == YAMD_DECODE_POSE) ? 5 + 3 * point_num + 1 : (kind == YAMD_DECODE_FACE ? 5 + 2 * point_num + 1 : 6);
+    YAMD_REQUIRE(c >= need && point_num >= 0, "c=%d too small for kind %d with %d points", c, kind, point_num);
+    const size_t lds = (size_t)PIX * na * c * sizeof(float);
+    YAMD_REQUIRE(lds <= 64 * 1024, "na*c=%d too large for the decode tile", na * c);
+    AnchorDecodeParams p;
+    p.raw = raw;
+    p.out = out;
+    p.H = h;
+    p.W = w;
+    p.na = na;
+    p.C = c;
+    p.kind = kind;
+    p.P = point_num;
+    p.stride = stride;
+    p.merge = merge ? 1 : 0;
+    p.clamp_points = clamp_points ? 1 : 0;
+    p.hi = img_size - 1.0f;
+    for (int a = 0; a < 8; ++a) {
+        p.aw[a] = a < na ? anchors_wh_host[2 * a] / (float)stride : 0.0f;
+        p.ah[a] = a < na ? anchors_wh_host[2 * a + 1] / (float)stride : 0.0f;
+    }
+    if (merge) {
+        YAMD_REQUIRE(rows_per_image >= row_offset + (long long)na * h * w && row_offset >= 0, "merged rows out of range");
+        p.rows_per_image = rows_per_image;
+        p.row_offset = row_offset;
+    } else {
+        p.rows_per_image = (long long)na * h * w;
+        p.row_offset = 0;
+    }
+    hipLaunchKernelGGL(decode_anchor_kernel, dim3(ceil_div((long long)h * w, PIX), batch), dim3(256), lds,
+                       (hipStream_t)stream, p);
+    YAMD_LAUNCH_CHECK();
+    return YAMD_OK;
+}
+
+extern "C" int yamd_decode_dfl(const float *const *raw_host_ptrs, const int *hs, const int *ws, const int *strides,
+                               int n_levels, int batch, int reg_max, int nc, int out_cxcywh, float *out, void *stream)
+{
+    YAMD_REQUIRE(raw_host_ptrs && hs && ws && strides && out, "null argument");
+    YAMD_REQUIRE(n_levels > 0 && n_levels <= 8 && batch > 0 && batch <= 65535 && reg_max > 0 && nc > 0, "bad shape");
+    long long rows = 0;
+    for (int i = 0; i < n_levels; ++i) rows += (long long)hs[i] * ws[i];
+    const size_t lds = (size_t)DPIX * (4 * reg_max + nc + 5 + nc) * sizeof(float);
+    YAMD_REQUIRE(lds <= 64 * 1024, "reg_max/nc too large for the DFL tile");
+    long long off = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        YAMD_REQUIRE(raw_host_ptrs[i] != nullptr && hs[i] > 0 && ws[i] > 0, "bad level %d", i);
+        DflParams p;
+        p.raw = raw_host_ptrs[i];
+        p.out = out;
+        p.H = hs[i];
+        p.W = ws[i];
+        p.reg_max = reg_max;
+        p.nc = nc;
+        p.stride = strides[i];
+        p.out_cxcywh = out_cxcywh ? 1 : 0;
+        p.rows_per_image = rows;
+        p.row_offset = off;
+        hipLaunchKernelGGL(decode_dfl_kernel, dim3(ceil_div((long long)hs[i] * ws[i], DPIX), batch), dim3(256), lds,
+                           (hipStream_t)stream, p);
+        YAMD_LAUNCH_CHECK();
+        off += (long long)hs[i] * ws[i];
+    }
+    return YAMD_OK;
+}

@@ -1,0 +1,198 @@
+"""Layer program for the conv graph: a recorded list of C-ABI calls over NHWC bf16 buffers.
+
+A model description (e.g. ``yolo_amd.yolov5``) walks its parameter tree once and records ops here;
+``Program.run`` then replays them for a batch.  Every activation is a *view* ``(buffer, channel
+offset, channels)`` so that ``torch.cat`` of the reference becomes "producers write their slice of a
+wider buffer" and costs nothing.  All arithmetic happens inside libyolo_amd.so; torch only owns the
+device memory and the stream.
+"""
+import ctypes
+from typing import Dict, List, NamedTuple, Optional, Tuple
+
+import torch
+
+from . import lib as _lib
+
+LIB = _lib.LIB
+
+
+class View(NamedTuple):
+    buf: str      # buffer name
+    coff: int     # first channel inside the buffer
+    c: int        # channels of the view
+    h: int
+    w: int
+
+    def slice(self, coff: int, c: int) -> "View":
+        assert 0 <= coff and coff + c <= self.c
+        return View(self.buf, self.coff + coff, c, self.h, self.w)
+
+
+class ConvLayer:
+    """One fused conv: descriptor + packed weights (host copies kept so any device can be fed)."""
+
+    def __init__(self, name: str, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, act: int,
+                 cin_stored: int, out_f32: bool):
+        w = weight.detach().to(torch.float32).cpu().contiguous()
+        cout, cin_real, k, k2 = w.shape
+        assert k == k2
+        self.name = name
+        self.cin_real = cin_real
+        self.macs_per_pixel = cout * cin_real * k * k
+        self.desc = _lib.ConvDesc()
+        _lib.check(LIB.yamd_conv_desc_init(ctypes.byref(self.desc), k, stride, cin_stored, cout, act, int(out_f32)),
+                   f"conv_desc_init[{name}]")
+        wp = torch.empty(self.desc.packed_w_elems, dtype=torch.int16)
+        bp = torch.empty(self.desc.cout_pad, dtype=torch.float32)
+        b = None if bias is None else bias.detach().to(torch.float32).cpu().contiguous()
+        _lib.check(LIB.yamd_conv_pack_weights(ctypes.byref(self.desc), w.data_ptr(), cin_real,
+                                              None if b is None else b.data_ptr(), wp.data_ptr(), bp.data_ptr()),
+                   f"conv_pack_weights[{name}]")
+        self.w_host, self.b_host = wp, bp
+        self.w_dev: Optional[torch.Tensor] = None
+        self.b_dev: Optional[torch.Tensor] = None
+
+    def to(self, device) -> None:
+        if self.w_dev is None or self.w_dev.device != torch.device(device):
+            self.w_dev = self.w_host.to(device)
+            self.b_dev = self.b_host.to(device)
+
+
+class Program:
+    def __init__(self, img_h: int, img_w: int):
+        self.img_h, self.img_w = img_h, img_w
+        self.buffers: Dict[str, Tuple[int, int, int, torch.dtype]] = {}
+        self.ops: List[tuple] = []
+        self.convs: List[ConvLayer] = []
+        self.outputs: Dict[str, View] = {}
+        self._alloc: Dict[Tuple[int, str], Dict[str, torch.Tensor]] = {}
+        self._n = 0
+
+    # ---- recording -------------------------------------------------------------------------------
+    def buffer(self, h: int, w: int, c: int, dtype=torch.bfloat16, name: Optional[str] = None) -> View:
+        self._n += 1
+        name = name or f"t{self._n}"
+        assert name not in self.buffers
+        self.buffers[name] = (h, w, c, dtype)
+        return View(name, 0, c, h, w)
+
+    def focus(self) -> View:
+        """fp32 NCHW images -> Focus space-to-depth, NHWC bf16, 12 channels padded to 16."""
+        y = self.buffer(self.img_h // 2, self.img_w // 2, 16, name="focus")
+        self.ops.append(("focus", y))
+        return y
+
+    def image16(self, cin: int = 3) -> View:
+        y = self.buffer(self.img_h, self.img_w, 16, name="image16")
+        self.ops.append(("nhwc16", y, cin))
+        return y
+
+    def conv(self, name: str, x: View, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, act: int,
+             out: Optional[View] = None, residual: Optional[View] = None, out_f32: bool = False) -> View:
+        k = weight.shape[-1]
+        cout = weight.shape[0]
+        layer = ConvLayer(name, weight, bias, stride, act, x.c, out_f32)
+        pad = k // 2
+        ho = (x.h + 2 * pad - k) // stride + 1
+        wo = (x.w + 2 * pad - k) // stride + 1
+        if out is None:
+            out = self.buffer(ho, wo, cout, torch.float32 if out_f32 else torch.bfloat16)
+        assert (out.h, out.w, out.c) == (ho, wo, cout), (name, out, ho, wo, cout)
+        if residual is not None:
+            assert (residual.h, residual.w, residual.c) == (ho, wo, cout)
+        self.convs.append(layer)
+        self.ops.append(("conv", layer, x, out, residual))
+        return out
+
+    def upsample2x(self, x: View, out: View) -> View:
+        assert (out.h, out.w, out.c) == (2 * x.h, 2 * x.w, x.c)
+        self.ops.append(("up2", x, out))
+        return out
+
+    def maxpool5_cascade(self, x: View, y1: View, y2: View, y3: View) -> None:
+        for y in (y1, y2, y3):
+            assert (y.h, y.w, y.c) == (x.h, x.w, x.c) and y.buf == y1.buf
+        self.ops.append(("mp5", x, y1, y2, y3))
+
+    def copy(self, x: View, out: View) -> View:
+        assert (out.h, out.w, out.c) == (x.h, x.w, x.c)
+        self.ops.append(("copy", x, out))
+        return out
+
+    # ---- accounting ------------------------------------------------------------------------------
+    def conv_macs_per_image(self) -> int:
+        total = 0
+        for op in self.ops:
+            if op[0] == "conv":
+                total += op[1].macs_per_pixel * op[3].h * op[3].w
+        return total
+
+    def activation_bytes_per_image(self) -> int:
+        return sum(h * w * c * (2 if dt == torch.bfloat16 else 4) for h, w, c, dt in self.buffers.values())
+
+    # ---- execution -------------------------------------------------------------------------------
+    def _buffers_for(self, batch: int, device) -> Dict[str, torch.Tensor]:
+        key = (batch, str(device))
+        if key not in self._alloc:
+            self._alloc.clear()   # one live batch size at a time: the arena is large
+            self._alloc[key] = {n: torch.empty((batch, h, w, c), dtype=dt, device=device)
+                                for n, (h, w, c, dt) in self.buffers.items()}
+            for layer in self.convs:
+                layer.to(device)
+        return self._alloc[key]
+
+    @staticmethod
+    def _ptr(bufs: Dict[str, torch.Tensor], v: View) -> Tuple[int, int]:
+        t = bufs[v.buf]
+        return t.data_ptr() + v.coff * t.element_size(), t.shape[-1]
+
+    def run(self, images: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """images: (B,3,H,W) float32 NCHW on the GPU.  Returns {output name: tensor view}; raw head
+        outputs are float32 NHWC ``(B,h,w,c)``.  Work is enqueued on torch's current stream."""
+        _lib.require_gpu(images, torch.float32, "images")
+        B, cin, H, W = images.shape
+        if (H, W) != (self.img_h, self.img_w):
+            raise _lib.YamdError(f"program was built for {self.img_h}x{self.img_w} images, got {H}x{W}")
+        bufs = self._buffers_for(B, images.device)
+        st = _lib.current_stream()
+        P = self._ptr
+        for op in self.ops:
+            kind = op[0]
+            if kind == "conv":
+                _, layer, x, out, res = op
+                xp, xcs = P(bufs, x)
+                yp, ycs = P(bufs, out)
+                rp, rcs = P(bufs, res) if res is not None else (None, 0)
+                _lib.check(LIB.yamd_conv2d_bias_act(ctypes.byref(layer.desc), xp, xcs, layer.w_dev.data_ptr(),
+                                                    layer.b_dev.data_ptr(), rp, rcs, yp, ycs, B, x.h, x.w, st),
+                           f"conv[{layer.name}]")
+            elif kind == "focus":
+                yp, ycs = P(bufs, op[1])
+                _lib.check(LIB.yamd_focus_pack(images.data_ptr(), yp, ycs, B, H, W, st), "focus")
+            elif kind == "nhwc16":
+                yp, ycs = P(bufs, op[1])
+                _lib.check(LIB.yamd_nchw_to_nhwc16(images.data_ptr(), yp, ycs, B, op[2], H, W, st), "nhwc16")
+            elif kind == "up2":
+                _, x, out = op
+                xp, xcs = P(bufs, x)
+                yp, ycs = P(bufs, out)
+                _lib.check(LIB.yamd_upsample2x(xp, xcs, yp, ycs, B, x.h, x.w, x.c, st), "upsample2x")
+            elif kind == "mp5":
+                _, x, y1, y2, y3 = op
+                xp, xcs = P(bufs, x)
+                p1, ycs = P(bufs, y1)
+                p2, _ = P(bufs, y2)
+                p3, _ = P(bufs, y3)
+                _lib.check(LIB.yamd_maxpool5_cascade(xp, xcs, p1, p2, p3, ycs, B, x.h, x.w, x.c, st), "maxpool5")
+            elif kind == "copy":
+                _, x, out = op
+                xp, xcs = P(bufs, x)
+                yp, ycs = P(bufs, out)
+                _lib.check(LIB.yamd_copy_channels(xp, xcs, yp, ycs, B * x.h * x.w, x.c, st), "copy")
+            else:
+                raise AssertionError(kind)
+        res = {}
+        for name, v in self.outputs.items():
+            t = bufs[v.buf]
+            res[name] = t if (v.coff == 0 and v.c == t.shape[-1]) else t[..., v.coff:v.coff + v.c]
+        return res

@@ -1,0 +1,94 @@
+"""ctypes binding of libyolo_amd.so (the C ABI declared in include/yolo_amd.h).
+
+There is deliberately no fallback: if the shared library is absent or a symbol is missing the
+import of this module raises, so a GPU test can never pass on a silent CPU path.
+"""
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_int32, c_int64, c_longlong, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolo_amd.so")
+
+ACT_NONE, ACT_SILU, ACT_LEAKY, ACT_MISH, ACT_RELU = 0, 1, 2, 3, 4
+DECODE_V5, DECODE_V3, DECODE_POSE, DECODE_FACE = 0, 1, 2, 3
+
+# every symbol include/yolo_amd.h declares
+EXPORTS = [
+    "yamd_last_error", "yamd_version", "yamd_conv_desc_init", "yamd_conv_pack_weights", "yamd_conv2d_bias_act",
+    "yamd_focus_pack", "yamd_nchw_to_nhwc16", "yamd_upsample2x", "yamd_maxpool5_cascade", "yamd_copy_channels",
+    "yamd_decode_anchor", "yamd_decode_dfl", "yamd_nms_workspace_bytes", "yamd_nms_batched",
+]
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of ``yamd_conv_desc``."""
+    _fields_ = [("ksize", c_int32), ("stride", c_int32), ("cin", c_int32), ("cout", c_int32), ("act", c_int32),
+                ("out_f32", c_int32), ("nrep", c_int32), ("ck", c_int32), ("mrep", c_int32), ("cout_pad", c_int32),
+                ("packed_w_elems", c_int64)]
+
+
+class YamdError(RuntimeError):
+    pass
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m yolo_amd.build` (hipcc, gfx950). "
+            "yolo_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise ImportError(f"{LIB_PATH} does not export {name}")
+    P = ctypes.POINTER
+    lib.yamd_last_error.restype = ctypes.c_char_p
+    lib.yamd_last_error.argtypes = []
+    lib.yamd_version.restype = c_int
+    lib.yamd_conv_desc_init.argtypes = [P(ConvDesc), c_int, c_int, c_int, c_int, c_int, c_int]
+    lib.yamd_conv_pack_weights.argtypes = [P(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p]
+    lib.yamd_conv2d_bias_act.argtypes = [P(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                         c_int, c_int, c_int, c_int, c_void_p]
+    lib.yamd_focus_pack.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
+    lib.yamd_nchw_to_nhwc16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.yamd_upsample2x.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.yamd_maxpool5_cascade.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                          c_int, c_void_p]
+    lib.yamd_copy_channels.argtypes = [c_void_p, c_int, c_void_p, c_int, c_longlong, c_int, c_void_p]
+    lib.yamd_decode_anchor.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
+                                       c_float, c_int, c_int, c_void_p, c_longlong, c_longlong, c_void_p]
+    lib.yamd_decode_dfl.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_void_p]
+    lib.yamd_nms_workspace_bytes.restype = c_size_t
+    lib.yamd_nms_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
+    lib.yamd_nms_batched.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_double, c_void_p,
+                                     c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("yamd_last_error", "yamd_nms_workspace_bytes"):
+            fn.restype = c_int
+    return lib
+
+
+LIB = _load()
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise YamdError(f"{what or 'yolo_amd call'} failed ({rc}): {LIB.yamd_last_error().decode()}")
+
+
+def current_stream() -> int:
+    """Raw hipStream_t of torch's current stream (0 = default stream)."""
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(t: torch.Tensor, dtype=None, name: str = "tensor") -> None:
+    if not t.is_cuda:
+        raise YamdError(f"{name} must live on the GPU: yolo_amd has no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise YamdError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise YamdError(f"{name} must be contiguous")

@@ -1,0 +1,158 @@
+"""Drop-in counterparts of luoyang/utils/torch_utils.py for the inference path.
+
+``non_max_suppression*`` keep the reference signatures and return type
+(``List[Optional[Tensor]]``, ``None`` for an image without candidates) but run the whole batch in
+the HIP kernels behind ``yamd_nms_batched`` -- no per-image Python loop, one device->host copy of
+the counts.  ``fuse_conv_and_bn`` is the host-side BatchNorm folding used when a plan is compiled.
+"""
+import ctypes
+from typing import List, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import lib as _lib
+
+LIB = _lib.LIB
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = str(device)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def nms_batched(prediction: torch.Tensor, img_size: float, in_fmt: str, conf_threshold: float,
+                nms_threshold: float, n_extra: int = 0, max_out: Optional[int] = None,
+                want_index: bool = False) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    """Device-side result: rows (B, max_out, 7+n_extra) float32, counts (B,) int32, index (B, max_out) int32."""
+    _lib.require_gpu(prediction, torch.float32, "prediction")
+    if prediction.dim() != 3:
+        raise _lib.YamdError("prediction must be (batch, anchors, columns)")
+    if in_fmt not in ("cxcywh", "xyxy"):
+        raise ValueError(f"unsupported in_fmt {in_fmt}")
+    B, A, C = prediction.shape
+    max_out = A if max_out is None else int(max_out)
+    dev = prediction.device
+    rows = torch.empty((B, max_out, 7 + n_extra), dtype=torch.float32, device=dev)
+    counts = torch.empty((B,), dtype=torch.int32, device=dev)
+    index = torch.empty((B, max_out), dtype=torch.int32, device=dev) if want_index else None
+    nbytes = LIB.yamd_nms_workspace_bytes(B, A, C, n_extra)
+    if nbytes == 0:
+        raise _lib.YamdError(f"bad NMS shape B={B} A={A} C={C} extra={n_extra}")
+    ws = _workspace(nbytes, dev)
+    # the comparison 'score >= conf_threshold' is done in float32, as torch does for a python scalar
+    conf32 = float(torch.tensor(conf_threshold, dtype=torch.float32))
+    _lib.check(LIB.yamd_nms_batched(prediction.data_ptr(), B, A, C, 1 if in_fmt == "cxcywh" else 0, n_extra,
+                                    float(img_size), conf32, float(nms_threshold), rows.data_ptr(),
+                                    None if index is None else index.data_ptr(), max_out, counts.data_ptr(),
+                                    ws.data_ptr(), ws.numel(), _lib.current_stream()), "nms_batched")
+    return rows, counts, index
+
+
+def _split(rows: torch.Tensor, counts: torch.Tensor) -> List[Optional[torch.Tensor]]:
+    host_counts = counts.cpu().tolist()        # the single synchronisation of the call
+    max_out = rows.shape[1]
+    return [None if k == 0 else rows[b, :min(k, max_out)] for b, k in enumerate(host_counts)]
+
+
+def non_max_suppression(prediction: torch.Tensor, img_size: float, in_fmt: str = "cxcywh",
+                        conf_threshold: float = 0.5, nms_threshold: float = 0.3
+                        ) -> List[Union[None, torch.Tensor]]:
+    """luoyang/utils/torch_utils.py:101-141.  Rows: [x1,y1,x2,y2,obj_conf,class_conf,class_id]."""
+    rows, counts, _ = nms_batched(prediction, img_size, in_fmt, conf_threshold, nms_threshold, 0)
+    return _split(rows, counts)
+
+
+def non_max_suppression_with_point(prediction: torch.Tensor, img_size: float, point_num: int,
+                                   in_fmt: str = "cxcywh", conf_threshold: float = 0.5,
+                                   nms_threshold: float = 0.3) -> List[Union[None, torch.Tensor]]:
+    """luoyang/utils/torch_utils.py:144-191.  Rows: [box, obj, class_conf, 2*P points, class_id]."""
+    rows, counts, _ = nms_batched(prediction, img_size, in_fmt, conf_threshold, nms_threshold, 2 * point_num)
+    return _split(rows, counts)
+
+
+def non_max_suppression_with_point_conf(prediction: torch.Tensor, img_size: float, point_num: int,
+                                        in_fmt: str = "cxcywh", conf_threshold: float = 0.5,
+                                        nms_threshold: float = 0.3) -> List[Union[None, torch.Tensor]]:
+    """luoyang/utils/torch_utils.py:194-241.  Rows: [box, obj, class_conf, 2*P points, P point conf, class_id]."""
+    rows, counts, _ = nms_batched(prediction, img_size, in_fmt, conf_threshold, nms_threshold, 3 * point_num)
+    return _split(rows, counts)
+
+
+def decode_anchor_levels(raws: List[torch.Tensor], anchors, strides, img_size: int, kind: int, point_num: int = 0,
+                         clamp_points: bool = False) -> torch.Tensor:
+    """raws[i]: (B,h,w,na*C) float32 NHWC head logits, ordered like ``strides``.  Returns the merged
+    (B, A, C) tensor of the reference's ``_forward`` (cxcywh, input pixels)."""
+    B = raws[0].shape[0]
+    na = len(anchors) // len(raws)
+    C = raws[0].shape[-1] // na
+    A = sum(na * r.shape[1] * r.shape[2] for r in raws)
+    out = torch.empty((B, A, C), dtype=torch.float32, device=raws[0].device)
+    off = 0
+    st = _lib.current_stream()
+    for i, (r, s) in enumerate(zip(raws, strides)):
+        _lib.require_gpu(r, torch.float32, "raw head")
+        wh = (ctypes.c_float * (2 * na))(*[float(v) for a in anchors[i * na:(i + 1) * na] for v in a])
+        _lib.check(LIB.yamd_decode_anchor(kind, r.data_ptr(), B, r.shape[1], r.shape[2], na, C, wh, int(s), point_num,
+                                          float(img_size), 1, int(clamp_points), out.data_ptr(), A, off, st),
+                   "decode_anchor")
+        off += na * r.shape[1] * r.shape[2]
+    return out
+
+
+def decode_anchor_head(raw: torch.Tensor, anchors, stride: int, kind: int, point_num: int = 0) -> torch.Tensor:
+    """One head module's output: (B, na, h, w, C) in grid units (e.g. yolov5/YoloV5Head.py:23-60)."""
+    _lib.require_gpu(raw, torch.float32, "raw head")
+    B, h, w, ch = raw.shape
+    na = len(anchors)
+    C = ch // na
+    out = torch.empty((B, na, h, w, C), dtype=torch.float32, device=raw.device)
+    wh = (ctypes.c_float * (2 * na))(*[float(v) for a in anchors for v in a])
+    _lib.check(LIB.yamd_decode_anchor(kind, raw.data_ptr(), B, h, w, na, C, wh, int(stride), point_num, 0.0, 0, 0,
+                                      out.data_ptr(), 0, 0, _lib.current_stream()), "decode_anchor")
+    return out
+
+
+def decode_dfl(raws: List[torch.Tensor], strides, reg_max: int, nc: int, out_fmt: str) -> torch.Tensor:
+    """raws[i]: (B,h,w,4*reg_max+nc) float32 NHWC.  Returns (B, A, 5+nc): [box, max score, scores]."""
+    B = raws[0].shape[0]
+    n = len(raws)
+    for r in raws:
+        _lib.require_gpu(r, torch.float32, "raw head")
+    A = sum(r.shape[1] * r.shape[2] for r in raws)
+    out = torch.empty((B, A, 5 + nc), dtype=torch.float32, device=raws[0].device)
+    ptrs = (ctypes.c_void_p * n)(*[r.data_ptr() for r in raws])
+    hs = (ctypes.c_int * n)(*[r.shape[1] for r in raws])
+    ws = (ctypes.c_int * n)(*[r.shape[2] for r in raws])
+    ss = (ctypes.c_int * n)(*[int(s) for s in strides])
+    _lib.check(LIB.yamd_decode_dfl(ptrs, hs, ws, ss, n, B, reg_max, nc, 1 if out_fmt == "cxcywh" else 0,
+                                   out.data_ptr(), _lib.current_stream()), "decode_dfl")
+    return out
+
+
+def fold_conv_bn(conv_w: torch.Tensor, conv_b: Optional[torch.Tensor], bn: nn.BatchNorm2d
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """W' = diag(g/sqrt(var+eps)) W ; b' = beta - g*mean/sqrt(var+eps) + diag(..) b  (eval-mode BN)."""
+    scale = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+    w = conv_w.detach().double() * scale.view(-1, 1, 1, 1)
+    b = bn.bias.detach().double() - bn.running_mean.detach().double() * scale
+    if conv_b is not None:
+        b = b + conv_b.detach().double() * scale
+    return w.float(), b.float()
+
+
+def fuse_conv_and_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d) -> nn.Conv2d:
+    """luoyang/utils/torch_utils.py:344-370: a Conv2d with bias equivalent to bn(conv(x)) in eval mode."""
+    assert isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d)
+    fused = nn.Conv2d(conv.in_channels, conv.out_channels, kernel_size=conv.kernel_size, stride=conv.stride,
+                      padding=conv.padding, groups=conv.groups, bias=True).requires_grad_(False).to(conv.weight.device)
+    w, b = fold_conv_bn(conv.weight, conv.bias, bn)
+    fused.weight.copy_(w)
+    fused.bias.copy_(b)
+    return fused
