@@ -1,0 +1,177 @@
+"""GPU parity tests of the individual kernels, called through the C ABI (ctypes) on cuda:0.
+
+conv: against torch-CPU fp32 conv2d on the same bf16-rounded inputs and weights; the only
+differences are fp32 accumulation order and the final bf16 rounding of the output:
+relative L2 <= 4e-3 and max-abs <= 1.5e-2 * max|y| are enforced.
+layout / pool / upsample kernels: exact.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_round(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _act(y, act):
+    if act == 1:
+        return y * torch.sigmoid(y)
+    if act == 2:
+        return F.leaky_relu(y, 0.1)
+    if act == 3:
+        return y * torch.tanh(F.softplus(y))
+    if act == 4:
+        return F.relu(y)
+    return y
+
+
+def _run_conv(dev, x, w, b, k, s, act, res=None, out_f32=False, in_extra=0, out_extra=0):
+    """x (B,Cin,H,W) fp32 (already bf16-representable); returns (B,Cout,Ho,Wo) fp32 from the HIP kernel.
+    in_extra/out_extra: additional channels around the tensor inside a wider buffer (cstride test)."""
+    from yolo_amd import lib as L
+    Bn, cin, H, W = x.shape
+    cout = w.shape[0]
+    cin_st = (cin + 15) // 16 * 16
+    d = L.ConvDesc()
+    L.check(L.LIB.yamd_conv_desc_init(ctypes.byref(d), k, s, cin_st, cout, act, int(out_f32)))
+    wp = torch.empty(d.packed_w_elems, dtype=torch.int16)
+    bp = torch.empty(d.cout_pad, dtype=torch.float32)
+    wc, bc = w.contiguous(), b.contiguous()
+    L.check(L.LIB.yamd_conv_pack_weights(ctypes.byref(d), wc.data_ptr(), cin, bc.data_ptr(), wp.data_ptr(), bp.data_ptr()))
+    xin = torch.zeros((Bn, H, W, cin_st + in_extra), dtype=torch.bfloat16)
+    xin[..., in_extra:in_extra + cin] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    if in_extra:
+        xin[..., :in_extra] = 7.0     # neighbours in the concat buffer must not leak in
+    xin = xin.to(dev)
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    ydt = torch.float32 if out_f32 else torch.bfloat16
+    y = torch.full((Bn, Ho, Wo, cout + out_extra), -3.0, dtype=ydt, device=dev)
+    rp, rcs = None, 0
+    if res is not None:
+        rt = res.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous().to(dev)
+        rp, rcs = rt.data_ptr(), cout
+    wd, bd = wp.to(dev), bp.to(dev)
+    L.check(L.LIB.yamd_conv2d_bias_act(ctypes.byref(d), xin.data_ptr() + in_extra * 2, xin.shape[-1], wd.data_ptr(),
+                                       bd.data_ptr(), rp, rcs, y.data_ptr() + out_extra * y.element_size(),
+                                       y.shape[-1], Bn, H, W, L.current_stream()), "conv")
+    torch.cuda.synchronize()
+    yc = y.cpu().float()
+    if out_extra:
+        assert torch.all(yc[..., :out_extra] == -3.0), "conv wrote outside its channel slice"
+    return yc[..., out_extra:].permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # k, s, cin, cout, H, W, act, residual, out_f32   (covers every built tiling, both tile widths, ragged edges)
+    (1, 1, 32, 32, 16, 16, 1, False, False),
+    (1, 1, 32, 64, 20, 20, 1, False, False),
+    (1, 1, 32, 128, 9, 13, 1, False, False),
+    (1, 1, 64, 32, 32, 32, 1, False, False),
+    (1, 1, 128, 64, 40, 40, 1, False, False),
+    (1, 1, 256, 128, 20, 20, 1, True, False),
+    (1, 1, 1024, 512, 20, 20, 1, False, False),
+    (1, 1, 128, 75, 16, 16, 0, False, True),
+    (1, 1, 256, 75, 20, 20, 0, False, True),
+    (1, 1, 512, 171, 10, 10, 0, False, True),
+    (3, 1, 12, 32, 32, 32, 1, False, False),
+    (3, 1, 16, 128, 20, 20, 2, False, False),
+    (3, 1, 32, 32, 24, 40, 1, True, False),
+    (3, 1, 64, 64, 17, 19, 1, True, False),
+    (3, 1, 128, 128, 40, 40, 1, True, False),
+    (3, 1, 256, 256, 20, 20, 3, False, False),
+    (3, 2, 32, 64, 32, 32, 1, False, False),
+    (3, 2, 64, 128, 40, 40, 1, False, False),
+    (3, 2, 128, 256, 23, 31, 4, False, False),
+    (3, 2, 256, 512, 40, 40, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("k,s,cin,cout,H,W,act,use_res,out_f32", CONV_CASES)
+def test_conv_parity(gpu_device, k, s, cin, cout, H, W, act, use_res, out_f32):
+    g = torch.Generator().manual_seed(k * 1000 + cin + cout + H)
+    Bn = 3
+    x = _bf16_round(torch.randn((Bn, cin, H, W), generator=g))
+    w = _bf16_round(torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+    b = torch.randn((cout,), generator=g) * 0.5
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    res = _bf16_round(torch.randn((Bn, cout, Ho, Wo), generator=g)) if use_res else None
+    want = _act(F.conv2d(x, w, b, stride=s, padding=k // 2), act)
+    if res is not None:
+        want = want + res
+    got = _run_conv(gpu_device, x, w, b, k, s, act, res, out_f32, in_extra=16 if cin % 16 == 0 else 0,
+                    out_extra=8 if not out_f32 else 3)
+    assert got.shape == want.shape
+    err = (got - want).double()
+    rel_l2 = float(err.norm() / want.double().norm())
+    max_abs = float(err.abs().max())
+    tol_l2, tol_abs = (1e-4, 1e-3) if out_f32 else (4e-3, 1.5e-2)
+    assert rel_l2 <= tol_l2, f"rel L2 {rel_l2}"
+    assert max_abs <= tol_abs * float(want.abs().max()), f"max abs {max_abs} vs {float(want.abs().max())}"
+
+
+def test_conv_identity_asymmetric(gpu_device):
+    """1x1 identity weights with an asymmetric input: catches any row/column or k-order permutation exactly."""
+    cin = cout = 64
+    x = torch.arange(2 * cin * 5 * 7, dtype=torch.float32).reshape(2, cin, 5, 7) % 251 - 125
+    w = torch.eye(cout).reshape(cout, cin, 1, 1)
+    got = _run_conv(gpu_device, x, w, torch.zeros(cout), 1, 1, 0)
+    assert torch.equal(got, x)
+    # 3x3 with a single off-centre tap = pure spatial shift (checks tap order and zero padding)
+    w3 = torch.zeros(cout, cin, 3, 3)
+    w3[torch.arange(cout), torch.arange(cin), 0, 2] = 1.0
+    got = _run_conv(gpu_device, x, w3, torch.zeros(cout), 3, 1, 0)
+    want = F.conv2d(x, w3, padding=1)
+    assert torch.equal(got, want)
+    got = _run_conv(gpu_device, x, w3, torch.zeros(cout), 3, 2, 0)
+    assert torch.equal(got, F.conv2d(x, w3, stride=2, padding=1))
+
+
+def test_focus_pack(gpu_device):
+    from yolo_amd import lib as L
+    img = torch.rand(2, 3, 12, 20)
+    y = torch.full((2, 6, 10, 16), 9.0, dtype=torch.bfloat16, device=gpu_device)
+    d = img.to(gpu_device)
+    L.check(L.LIB.yamd_focus_pack(d.data_ptr(), y.data_ptr(), 16, 2, 12, 20, L.current_stream()))
+    torch.cuda.synchronize()
+    want = torch.cat([img[..., ::2, ::2], img[..., 1::2, ::2], img[..., ::2, 1::2], img[..., 1::2, 1::2]], 1)
+    want = want.permute(0, 2, 3, 1).to(torch.bfloat16)
+    got = y.cpu()
+    assert torch.equal(got[..., :12], want) and torch.all(got[..., 12:] == 0)
+
+
+def test_upsample_copy_maxpool(gpu_device):
+    from yolo_amd import lib as L
+    st = L.current_stream()
+    x = torch.randn(2, 5, 7, 24).to(torch.bfloat16)
+    xd = x.to(gpu_device)
+    y = torch.zeros((2, 10, 14, 40), dtype=torch.bfloat16, device=gpu_device)
+    L.check(L.LIB.yamd_upsample2x(xd.data_ptr() + 8 * 2, 24, y.data_ptr() + 16 * 2, 40, 2, 5, 7, 16, st))
+    z = torch.zeros((2, 5, 7, 32), dtype=torch.bfloat16, device=gpu_device)
+    L.check(L.LIB.yamd_copy_channels(xd.data_ptr(), 24, z.data_ptr() + 8 * 2, 32, 2 * 5 * 7, 24, st))
+    # SPP: x in slice 0 of a 4-slice buffer, pools 5/9/13 into the others
+    H = W = 20
+    c = 16
+    cat = torch.zeros((3, H, W, 4 * c), dtype=torch.bfloat16)
+    src = torch.randn(3, H, W, c).to(torch.bfloat16)
+    cat[..., :c] = src
+    cd = cat.to(gpu_device)
+    p = cd.data_ptr()
+    L.check(L.LIB.yamd_maxpool5_cascade(p, 4 * c, p + c * 2, p + 2 * c * 2, p + 3 * c * 2, 4 * c, 3, H, W, c, st))
+    torch.cuda.synchronize()
+    up = x[..., 8:24].float().permute(0, 3, 1, 2)
+    want_up = F.interpolate(up, scale_factor=2, mode="nearest").permute(0, 2, 3, 1).to(torch.bfloat16)
+    got = y.cpu()
+    assert torch.equal(got[..., 16:32], want_up) and torch.all(got[..., :16] == 0) and torch.all(got[..., 32:] == 0)
+    assert torch.equal(z.cpu()[..., 8:32], x)
+    s = src.float().permute(0, 3, 1, 2)
+    got = cd.cpu()
+    assert torch.equal(got[..., :c], src)
+    for i, k in enumerate((5, 9, 13)):
+        want = F.max_pool2d(s, k, 1, k // 2).permute(0, 2, 3, 1).to(torch.bfloat16)
+        assert torch.equal(got[..., (i + 1) * c:(i + 2) * c], want), f"pool {k}"

@@ -1,0 +1,157 @@
+"""GPU parity of decode and NMS through the C ABI.
+
+decode: <= 1e-5 relative (+1e-5 abs) against the reference's golden tensors and the numpy oracle on
+identical fp32 logits (exp/sigmoid ulp differences only).
+NMS: rows and kept source indices bit-identical to the golden rows of the reference and to the C
+oracle, including order; images without candidates give count 0 (the reference's None).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_rows
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-5, 1e-5
+
+
+def _nhwc(raw, dev):
+    return torch.from_numpy(np.ascontiguousarray(raw.transpose(0, 2, 3, 1))).to(dev)
+
+
+def test_decode_anchor_kinds_vs_golden(gpu_device):
+    from yolo_amd import lib as L, param as P, torch_utils as tu
+    G = load_golden("decode.npz")
+    p5, p3, pp, pf = P.Yolo5Param(m_type="s"), P.Yolo3Param(), P.Yolo7PoseParam(), P.Yolo7FaceParam()
+    raws = [_nhwc(G[f"v5_raw{i}"], gpu_device) for i in range(3)]
+    got = tu.decode_anchor_levels(raws, p5.anchors, p5.strides, 64, L.DECODE_V5).cpu().numpy()
+    np.testing.assert_allclose(got, G["v5_pred"], rtol=RTOL, atol=ATOL)
+    h3 = tu.decode_anchor_head(raws[0], p5.anchors[:3], 8, L.DECODE_V5).cpu().numpy()
+    np.testing.assert_allclose(h3, G["v5_head3"], rtol=RTOL, atol=ATOL)
+    raws = [_nhwc(G[f"v3_raw{i}"], gpu_device) for i in range(3)]
+    got = tu.decode_anchor_levels(raws, p3.anchors, p3.strides, 64, L.DECODE_V3).cpu().numpy()
+    np.testing.assert_allclose(got, G["v3_pred"], rtol=RTOL, atol=ATOL)
+    raws = [_nhwc(G[f"pose_raw{i}"], gpu_device) for i in range(3)]
+    got = tu.decode_anchor_levels(raws, pp.anchors, pp.strides, 64, L.DECODE_POSE, 17).cpu().numpy()
+    np.testing.assert_allclose(got, G["pose_pred"], rtol=RTOL, atol=ATOL)
+    for i in range(3):
+        r = _nhwc(G[f"face_raw{i}"], gpu_device)
+        got = tu.decode_anchor_head(r, pf.anchors[3 * i:3 * i + 3], pf.strides[i], L.DECODE_FACE, 5).cpu().numpy()
+        np.testing.assert_allclose(got, G[f"face_head{i}"], rtol=RTOL, atol=ATOL)
+
+
+def test_decode_dfl_vs_golden(gpu_device):
+    from yolo_amd import torch_utils as tu
+    G = load_golden("decode.npz")
+    raws = [_nhwc(G[f"v8_raw{i}"], gpu_device) for i in range(3)]
+    got = tu.decode_dfl(raws, [8, 16, 32], 16, 20, "cxcywh").cpu().numpy()
+    np.testing.assert_allclose(got, G["v8_pred_cxcywh"], rtol=RTOL, atol=2e-5)
+    got = tu.decode_dfl(raws, [8, 16, 32], 16, 20, "xyxy").cpu().numpy()
+    np.testing.assert_allclose(got, G["v8_pred_xyxy"], rtol=RTOL, atol=2e-5)
+
+
+def test_decode_ragged_sizes_vs_oracle(gpu_device):
+    """odd feature sizes (19x19, 5x3): unaligned rows, partial tiles."""
+    from oracle import decode_ref as D
+    from yolo_amd import lib as L, torch_utils as tu
+    rng = np.random.RandomState(3)
+    anchors = [(10, 13), (16, 30), (33, 23)]
+    for (h, w, C, kind, name, P) in ((19, 19, 25, L.DECODE_V5, "v5", 0), (5, 3, 85, L.DECODE_V3, "v3", 0),
+                                     (7, 9, 57, L.DECODE_POSE, "pose", 17), (3, 11, 16, L.DECODE_FACE, "face", 5)):
+        raw = (rng.standard_normal((2, 3 * C, h, w)) * 2).astype(np.float32)
+        want = D.decode_anchor_level(raw, anchors, 16, name, P)
+        got = tu.decode_anchor_head(_nhwc(raw, gpu_device), anchors, 16, kind, P).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+
+
+def _check_rows(got_rows, got_counts, want, got_index=None, want_index=None):
+    counts = got_counts.cpu().tolist()
+    rows = got_rows.cpu().numpy()
+    idx = None if got_index is None else got_index.cpu().numpy()
+    assert len(counts) == len(want)
+    for b, w in enumerate(want):
+        if w is None:
+            assert counts[b] == 0, f"image {b}: expected no detections, got {counts[b]}"
+            continue
+        assert counts[b] == w.shape[0], f"image {b}: kept {counts[b]} vs {w.shape[0]}"
+        g = rows[b, :counts[b]]
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), f"image {b}: rows differ"
+        if want_index is not None:
+            assert np.array_equal(idx[b, :counts[b]].astype(np.int64), want_index[b]), f"image {b}: kept indices differ"
+
+
+def test_nms_vs_reference_golden(gpu_device):
+    from oracle import postprocess as pp
+    from yolo_amd import torch_utils as tu
+    G = load_golden("nms.npz")
+    for name in [str(c) for c in G["cases"]]:
+        pred = G[f"{name}__pred"]
+        img, cx, conf, nms, P, pc = G[f"{name}__meta"].tolist()
+        n_extra = int(P) * (3 if pc else 2)
+        fmt = "cxcywh" if cx else "xyxy"
+        rows, counts, index = tu.nms_batched(torch.from_numpy(pred).to(gpu_device), img, fmt, conf, nms, n_extra,
+                                             want_index=True)
+        want = split_rows(G[f"{name}__counts"], G[f"{name}__rows"])
+        _, want_idx = pp.non_max_suppression(pred, img, fmt, conf, nms, point_num=int(P), point_conf=bool(pc),
+                                             return_index=True)
+        _check_rows(rows, counts, want, index, want_idx)
+
+
+def test_nms_public_signatures(gpu_device):
+    from yolo_amd import torch_utils as tu
+    G = load_golden("nms.npz")
+    pred = torch.from_numpy(G["none_images__pred"]).to(gpu_device)
+    out = tu.non_max_suppression(pred, img_size=320.0, conf_threshold=0.25, nms_threshold=0.3)
+    want = split_rows(G["none_images__counts"], G["none_images__rows"])
+    assert out[0] is None and out[2] is None
+    assert np.array_equal(out[1].cpu().numpy(), want[1])
+    pred = torch.from_numpy(G["face5__pred"]).to(gpu_device)
+    out = tu.non_max_suppression_with_point(pred, 640.0, 5, conf_threshold=0.3, nms_threshold=0.3)
+    assert out[0].shape[1] == 17
+    pred = torch.from_numpy(G["pose17__pred"]).to(gpu_device)
+    out = tu.non_max_suppression_with_point_conf(pred, 640.0, 17, conf_threshold=0.3, nms_threshold=0.3)
+    assert out[0].shape[1] == 58
+
+
+@pytest.mark.parametrize("B,A,nc,clusters,conf", [(4, 2500, 20, 40, 0.1), (2, 6000, 3, 25, 0.05), (3, 1000, 80, 10, 0.2)])
+def test_nms_random_vs_c_oracle(gpu_device, B, A, nc, clusters, conf):
+    """larger seeded sets: multi-tile sweeps, segments > 256 boxes, many classes"""
+    from oracle import postprocess as pp
+    from oracle.gen_golden_synth import synthetic_pred
+    from yolo_amd import torch_utils as tu
+    rng = np.random.RandomState(B * 7 + A)
+    pred = synthetic_pred(rng, B, A, nc, 640.0, clusters=clusters)
+    want, want_idx = pp.non_max_suppression(pred, 640.0, "cxcywh", conf, 0.3, return_index=True)
+    rows, counts, index = tu.nms_batched(torch.from_numpy(pred).to(gpu_device), 640.0, "cxcywh", conf, 0.3, 0,
+                                         want_index=True)
+    _check_rows(rows, counts, want, index, want_idx)
+
+
+def test_nms_allpass_single_class_big_segment(gpu_device):
+    """every anchor passes and falls into ONE class: the longest sequential sweep (segment = A boxes)"""
+    from oracle import postprocess as pp
+    from yolo_amd import torch_utils as tu
+    g = 40
+    ys, xs = np.meshgrid(np.arange(g), np.arange(g), indexing="ij")
+    rng = np.random.RandomState(1)
+    box = np.concatenate([np.stack((xs.ravel() * 8 + 4.0, ys.ravel() * 8 + 4.0, np.full(g * g, aw), np.full(g * g, ah)), -1)
+                          for aw, ah in ((10, 13), (16, 30), (33, 23))], 0)[None]
+    A = box.shape[1]
+    obj = 0.5 + rng.uniform(-1e-3, 1e-3, (1, A, 1))
+    cls = np.concatenate((np.full((1, A, 1), 0.6), np.full((1, A, 3), 0.4)), -1)
+    pred = np.concatenate((box, obj, cls), -1).astype(np.float32)
+    want, want_idx = pp.non_max_suppression(pred, 320.0, "cxcywh", 0.1, 0.3, return_index=True)
+    rows, counts, index = tu.nms_batched(torch.from_numpy(pred).to(gpu_device), 320.0, "cxcywh", 0.1, 0.3, 0,
+                                         want_index=True)
+    _check_rows(rows, counts, want, index, want_idx)
+
+
+def test_nms_max_out_truncates_but_counts(gpu_device):
+    from yolo_amd import torch_utils as tu
+    G = load_golden("nms.npz")
+    pred = torch.from_numpy(G["clustered20__pred"]).to(gpu_device)
+    rows, counts, _ = tu.nms_batched(pred, 640.0, "cxcywh", 0.1, 0.3, 0, max_out=50)
+    want = split_rows(G["clustered20__counts"], G["clustered20__rows"])
+    assert counts.cpu().tolist() == [w.shape[0] for w in want]
+    for b, w in enumerate(want):
+        assert np.array_equal(rows[b].cpu().numpy(), w[:50])
