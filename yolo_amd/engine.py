@@ -130,6 +130,31 @@ class Program:
     def activation_bytes_per_image(self) -> int:
         return sum(h * w * c * (2 if dt == torch.bfloat16 else 4) for h, w, c, dt in self.buffers.values())
 
+    def op_cost(self, op, batch: int) -> Tuple[float, float]:
+        """(algorithmic flops, algorithmic bytes) of one recorded op for a batch: every input and output
+        element counted once (bf16 = 2 bytes), weights once."""
+        kind = op[0]
+        if kind == "conv":
+            _, layer, x, out, res = op
+            px = batch * out.h * out.w
+            flops = 2.0 * layer.macs_per_pixel * px
+            ob = 4 if layer.desc.out_f32 else 2
+            byts = batch * x.h * x.w * layer.cin_real * 2 + px * out.c * ob + layer.macs_per_pixel * 2
+            if res is not None:
+                byts += px * out.c * 2
+            return flops, float(byts)
+        if kind == "focus":
+            return 0.0, float(batch * self.img_h * self.img_w * 3 * 4 + batch * op[1].h * op[1].w * 16 * 2)
+        if kind == "nhwc16":
+            return 0.0, float(batch * self.img_h * self.img_w * (op[2] * 4 + 32))
+        if kind == "up2":
+            return 0.0, float(batch * op[1].h * op[1].w * op[1].c * 2 * 5)
+        if kind == "mp5":
+            return 0.0, float(batch * op[1].h * op[1].w * op[1].c * 2 * 4)
+        if kind == "copy":
+            return 0.0, float(batch * op[1].h * op[1].w * op[1].c * 2 * 2)
+        return 0.0, 0.0
+
     # ---- execution -------------------------------------------------------------------------------
     def _buffers_for(self, batch: int, device) -> Dict[str, torch.Tensor]:
         key = (batch, str(device))
@@ -146,9 +171,11 @@ class Program:
         t = bufs[v.buf]
         return t.data_ptr() + v.coff * t.element_size(), t.shape[-1]
 
-    def run(self, images: torch.Tensor) -> Dict[str, torch.Tensor]:
+    def run(self, images: torch.Tensor, timings: Optional[list] = None) -> Dict[str, torch.Tensor]:
         """images: (B,3,H,W) float32 NCHW on the GPU.  Returns {output name: tensor view}; raw head
-        outputs are float32 NHWC ``(B,h,w,c)``.  Work is enqueued on torch's current stream."""
+        outputs are float32 NHWC ``(B,h,w,c)``.  Work is enqueued on torch's current stream.
+        If ``timings`` is a list, every op is bracketed by events on that stream and
+        ``(kind, name, start_event, end_event, flops, bytes)`` tuples are appended (profiling aid)."""
         _lib.require_gpu(images, torch.float32, "images")
         B, cin, H, W = images.shape
         if (H, W) != (self.img_h, self.img_w):
@@ -158,6 +185,9 @@ class Program:
         P = self._ptr
         for op in self.ops:
             kind = op[0]
+            if timings is not None:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
             if kind == "conv":
                 _, layer, x, out, res = op
                 xp, xcs = P(bufs, x)
@@ -191,6 +221,10 @@ class Program:
                 _lib.check(LIB.yamd_copy_channels(xp, xcs, yp, ycs, B * x.h * x.w, x.c, st), "copy")
             else:
                 raise AssertionError(kind)
+            if timings is not None:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record()
+                timings.append((kind, op[1].name if kind == "conv" else kind, ev0, ev1) + self.op_cost(op, B))
         res = {}
         for name, v in self.outputs.items():
             t = bufs[v.buf]
