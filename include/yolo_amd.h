@@ -145,6 +145,13 @@ int yamd_nms_batched(const float *pred, int batch, int a, int c, int in_cxcywh, 
                      float conf_thr, double iou_thr, float *out_rows, int *out_index, int max_out,
                      int *out_counts, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Packs the kept rows of all images back to back for a single device->host copy; the counterpart of
+ * the per-image `.detach().cpu().numpy()` of yolov5/YoloV5.py:125-126.  compact: (sum_b min(count_b,
+ * max_out), width) float; offsets: (batch+1) int64, offsets[b] = first row of image b, offsets[batch] =
+ * total rows. */
+int yamd_compact_rows(const float *rows, const int *counts, int batch, int max_out, int width, float *compact,
+                      long long *offsets, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

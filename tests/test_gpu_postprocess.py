@@ -155,3 +155,13 @@ def test_nms_max_out_truncates_but_counts(gpu_device):
     assert counts.cpu().tolist() == [w.shape[0] for w in want]
     for b, w in enumerate(want):
         assert np.array_equal(rows[b].cpu().numpy(), w[:50])
+
+
+def test_rows_to_host_packs_like_reference_list(gpu_device):
+    from yolo_amd import torch_utils as tu
+    G = load_golden("nms.npz")
+    pred = torch.from_numpy(G["none_images__pred"]).to(gpu_device)
+    rows, counts, _ = tu.nms_batched(pred, 320.0, "cxcywh", 0.25, 0.3, 0)
+    got = tu.rows_to_host(rows, counts)
+    want = split_rows(G["none_images__counts"], G["none_images__rows"])
+    assert got[0] is None and got[2] is None and np.array_equal(got[1], want[1])

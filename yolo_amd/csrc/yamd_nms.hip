@@ -9,12 +9,13 @@
 //               global atomic per (workgroup, class).
 //   2. scan     exclusive prefix of the class counts per image.
 //   3. bucket   scatter keys into their class buckets (order inside a bucket is arbitrary).
-//   4. segment  one workgroup per (image, class): rank the bucket by counting (keys are unique, so
-//               the rank IS the position in the stable descending sort), write keys and class-offset
-//               boxes in sorted order, then run the greedy sweep in tiles of 64 boxes: wave 0
-//               resolves the tile with ballots (bit i of the mask = box i still alive), the kept
-//               boxes are broadcast through LDS and every wave clears the later boxes they suppress
-//               (one ballot -> one 64-bit word of the removed-bitmask in LDS per wave step).
+//   4. segment  one workgroup per (image, class): bitonic-sort the bucket's keys (keys are unique, so
+//               descending key order IS the stable descending score order), write keys and class-offset
+//               boxes in sorted order, then run the greedy sweep in tiles of 64 boxes: the tile is
+//               resolved with ballots (bit i of a mask = box i), the kept boxes are broadcast through
+//               LDS and every wave clears the later boxes they suppress (one ballot -> one 64-bit word
+//               of the removed-bitmask in LDS per wave step), skipping whole 64-box groups whose
+//               bounding box no kept box touches.
 //               Boxes of different classes never interact: their offset boxes are disjoint because
 //               img_size <= 4096, which is what adding cls*4096 achieves in the reference.
 //   5. gather   kept rows of an image are merged across classes into global descending-score order
@@ -39,7 +40,9 @@ struct NmsParams {
     int B, A, C, in_cxcywh, n_extra, nc, W, max_out;
     float hi, conf_thr, iou_thr;
     u64 *tmp_key, *tmp_meta, *bkey, *skey, *kseg;
-    float4 *sbox;
+    float4 *sbox, *mbox;
+    u32 *mrank, *posr;
+    int sort_cap;
     u32 *img_count, *cls_count, *cls_off, *kcnt;
     float *out_rows;
     int *out_index, *out_counts;
@@ -173,114 +176,218 @@ __device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy
     return ovr > thr;
 }
 
-constexpr int RANK_TILE = 1024;
-constexpr int RANK_R = 4;
+// In-place bitonic sort, descending, of n (any n) 64-bit keys by one 256-thread workgroup.  `a` may
+// point to LDS or to global memory.  The network only uses comparators that move the larger key to the
+// lower index (each merge starts with a mirror step), so the virtual padding "smaller than everything"
+// beyond n never has to move and needs no storage.
+__device__ void bitonic_sort_desc(u64 *a, u32 n, int tid)
+{
+    u32 npad = 1;
+    while (npad < n) npad <<= 1;
+    const u32 half = npad >> 1;
+    for (u32 k = 2; k <= npad; k <<= 1) {
+        const u32 h = k >> 1;
+        for (u32 c = tid; c < half; c += 256) {
+            const u32 i = ((c & ~(h - 1)) << 1) | (c & (h - 1));
+            const u32 l = i ^ (k - 1);
+            if (l < n) {
+                const u64 x = a[i], y = a[l];
+                if (x < y) { a[i] = y; a[l] = x; }
+            }
+        }
+        __syncthreads();
+        for (u32 j = k >> 2; j > 0; j >>= 1) {
+            for (u32 c = tid; c < half; c += 256) {
+                const u32 i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
+                const u32 l = i | j;
+                if (l < n) {
+                    const u64 x = a[i], y = a[l];
+                    if (x < y) { a[i] = y; a[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
 
+__device__ __forceinline__ u32 spread10(u32 v)   // 10 bits -> every second bit
+{
+    v &= 0x3ffu;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+__device__ __forceinline__ float rl(float v, int lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
+
+// One workgroup per (class, image) bucket.
+//  1. sort the bucket's keys (descending = the stable descending score order),
+//  2. write keys / class-offset boxes in that order, then order the same boxes along a Morton curve of
+//     their centres so that 64 consecutive boxes form a spatially compact GROUP with a small bounding box,
+//  3. greedy sweep in tiles of 64 score-consecutive boxes:
+//       A  all four waves compute the tile's 64x64 suppression matrix as 64 ballots (columns),
+//       B  wave 0 resolves the tile serially on scalar bit masks,
+//       C  every wave takes groups; the tile's kept boxes (one per lane) are first tested against the
+//          group's bounding box with one ballot, and only the few that can intersect it are applied to
+//          the group's boxes; results land in the removed-bitmask (one 64-bit word per group).
+//     The bounding-box test only skips pairs whose intersection is exactly empty, so the kept set is
+//     the one the plain greedy loop produces.
 __global__ __launch_bounds__(256) void nms_segment_kernel(NmsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_seg[];
-    u64 *tk = (u64 *)smem_seg;                         // RANK_TILE keys (8 KB); reused by the sweep
-    float4 *kb = (float4 *)smem_seg;                   // 64 kept boxes (aliases tk)
-    float *ka = (float *)(smem_seg + 64 * sizeof(float4));   // 64 kept areas
-    u32 *s_nk = (u32 *)(smem_seg + 64 * sizeof(float4) + 64 * sizeof(float));
-    u64 *rem = (u64 *)(smem_seg + RANK_TILE * sizeof(u64));  // removed bitmask, ceil(n/64) words
-
     const int cls = blockIdx.x;
     const long long b = blockIdx.y;
     const u32 n = p.cls_count[b * p.nc + cls];
     if (n == 0) return;
     const u32 off = p.cls_off[b * (p.nc + 1) + cls];
-    const u64 *keys = p.bkey + b * p.A + off;
-    u64 *skey = p.skey + b * p.A + off;
-    float4 *sbox = p.sbox + b * p.A + off;
-    u64 *kseg = p.kseg + b * p.A + off;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long base = b * p.A + off;
+    const u64 *keys = p.bkey + base;
+    u64 *skey = p.skey + base;
+    float4 *sbox = p.sbox + base;
+    u64 *kseg = p.kseg + base;
+    float4 *mbox = p.mbox + base;
+    u32 *mrank = p.mrank + base;
+    u32 *posr = p.posr + base;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float coff = (float)cls * 4096.0f;
 
-    // ---- rank by counting
-    for (u32 base = 0; base < n; base += 256 * RANK_R) {
-        u64 mk[RANK_R];
-        u32 cnt[RANK_R];
+    // ---- 1. sort by key: in LDS when the bucket fits, else in place in global memory (skey)
+    const bool in_lds = n <= (u32)p.sort_cap;
+    u64 *S = in_lds ? (u64 *)smem_seg : skey;
+    for (u32 i = tid; i < n; i += 256) S[i] = keys[i];
+    __syncthreads();
+    bitonic_sort_desc(S, n, tid);
+
+    // ---- 2. sorted keys + offset boxes out; Morton keys in
+    u64 *M = in_lds ? (u64 *)smem_seg : kseg;       // kseg is free until the sweep writes kept keys
+    const float qs = 1024.0f / (p.hi + 1.0f);
+    for (u32 r = tid; r < n; r += 256) {
+        const u64 key = S[r];
+        const u32 idx = 0xFFFFFFFFu - (u32)key;
+        float x1, y1, x2, y2;
+        row_box(p.pred + (b * p.A + idx) * (long long)p.C, p.in_cxcywh, p.hi, x1, y1, x2, y2);
+        skey[r] = key;
+        sbox[r] = make_float4(x1 + coff, y1 + coff, x2 + coff, y2 + coff);
+        const u32 qx = (u32)fminf(fmaxf((x1 + x2) * 0.5f * qs, 0.0f), 1023.0f);
+        const u32 qy = (u32)fminf(fmaxf((y1 + y2) * 0.5f * qs, 0.0f), 1023.0f);
+        M[r] = ((u64)(spread10(qx) | (spread10(qy) << 1)) << 32) | (u64)r;
+    }
+    __syncthreads();
+    bitonic_sort_desc(M, n, tid);
+    for (u32 s = tid; s < n; s += 256) {
+        const u32 r = (u32)M[s];
+        mrank[s] = r;
+        posr[r] = s;
+        mbox[s] = sbox[r];
+    }
+    __syncthreads();
+
+    // ---- sweep state in LDS (aliases the sort array)
+    const u32 ng = (n + 63) / 64;                       // groups == tiles == mask words
+    float4 *gbb = (float4 *)smem_seg;                   // ng group bounding boxes
+    float4 *kb = gbb + ng;                              // 64 kept boxes of the current tile
+    u64 *rem = (u64 *)(kb + 64);                        // ng removed-bit words (by Morton position)
+    u64 *colmask = rem + ng;                            // 64
+    u32 *gmax = (u32 *)(colmask + 64);                  // ng: largest score rank inside the group
+    float *ka = (float *)(gmax + ng);                   // 64 areas
+    u32 *s_nk = (u32 *)(ka + 64);
+    for (u32 g = wave; g < ng; g += 4) {
+        const u32 s = g * 64 + lane;
+        const bool v = s < n;
+        const float4 bx = v ? mbox[s] : make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+        float mnx = bx.x, mny = bx.y, mxx = bx.z, mxy = bx.w;
+        u32 mr = v ? mrank[s] : 0u;
 #pragma unroll
-        for (int r = 0; r < RANK_R; ++r) {
-            const u32 i = base + r * 256 + tid;
-            mk[r] = i < n ? keys[i] : ~0ull;   // ~0 is larger than any real key: counts nothing
-            cnt[r] = 0;
+        for (int d = 32; d > 0; d >>= 1) {
+            mnx = fminf(mnx, __shfl_xor(mnx, d));
+            mny = fminf(mny, __shfl_xor(mny, d));
+            mxx = fmaxf(mxx, __shfl_xor(mxx, d));
+            mxy = fmaxf(mxy, __shfl_xor(mxy, d));
+            mr = max(mr, (u32)__shfl_xor((int)mr, d));
         }
-        for (u32 t0 = 0; t0 < n; t0 += RANK_TILE) {
-            __syncthreads();
-            const u32 tn = min((u32)RANK_TILE, n - t0);
-            for (u32 j = tid; j < tn; j += 256) tk[j] = keys[t0 + j];
-            __syncthreads();
-            for (u32 j = 0; j < tn; ++j) {
-                const u64 k = tk[j];
-#pragma unroll
-                for (int r = 0; r < RANK_R; ++r) cnt[r] += (k > mk[r]) ? 1u : 0u;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < RANK_R; ++r) {
-            const u32 i = base + r * 256 + tid;
-            if (i < n) {
-                const u32 idx = 0xFFFFFFFFu - (u32)mk[r];
-                float x1, y1, x2, y2;
-                row_box(p.pred + (b * p.A + idx) * (long long)p.C, p.in_cxcywh, p.hi, x1, y1, x2, y2);
-                skey[cnt[r]] = mk[r];
-                sbox[cnt[r]] = make_float4(x1 + coff, y1 + coff, x2 + coff, y2 + coff);
-            }
+        if (lane == 0) {
+            gbb[g] = make_float4(mnx, mny, mxx, mxy);
+            gmax[g] = mr;
+            rem[g] = 0ull;
         }
     }
-    const u32 nwords = (n + 63) / 64;
-    for (u32 w = tid; w < nwords; w += 256) rem[w] = 0ull;
-    __syncthreads();   // sorted keys/boxes (global) and the cleared mask (LDS) are visible to the block
+    __syncthreads();
 
-    // ---- greedy sweep, 64 boxes per step
-    u32 nkept = 0;     // running count of kept boxes of this segment (uniform)
-    for (u32 t = 0; t < nwords; ++t) {
+    u32 nkept = 0;
+    for (u32 t = 0; t < ng; ++t) {
+        // A: column i of the tile's suppression matrix = lanes j > i that box i would remove
+        const u32 j = t * 64 + lane;
+        const bool inr = j < n;
+        const float4 bx = inr ? sbox[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float ar = (bx.z - bx.x) * (bx.w - bx.y);
+        bool alive = false;
+        if (wave == 0 && inr) {
+            const u32 sp = posr[j];
+            alive = !((rem[sp >> 6] >> (sp & 63)) & 1ull);
+        }
+        const u32 tn = min(64u, n - t * 64);
+#pragma unroll 4
+        for (int ii = 0; ii < 16; ++ii) {
+            const int i = wave * 16 + ii;
+            if ((u32)i >= tn) break;
+            const float ix1 = rl(bx.x, i), iy1 = rl(bx.y, i), ix2 = rl(bx.z, i), iy2 = rl(bx.w, i), ia = rl(ar, i);
+            const bool sup = inr && lane > i && iou_gt(ix1, iy1, ix2, iy2, ia, bx.x, bx.y, bx.z, bx.w, ar, p.iou_thr);
+            const u64 cm = __ballot(sup);
+            if (lane == 0) colmask[i] = cm;
+        }
+        __syncthreads();
+        // B: serial resolve on wave 0
         if (wave == 0) {
-            const u32 j = t * 64 + lane;
-            const bool inr = j < n;
-            float4 bx = inr ? sbox[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float ar = (bx.z - bx.x) * (bx.w - bx.y);
-            const bool alive = inr && !((rem[t] >> lane) & 1ull);
+            const u64 mycol = (u32)lane < tn ? colmask[lane] : 0ull;
+            const u32 clo = (u32)mycol, chi = (u32)(mycol >> 32);
             u64 m = __ballot(alive);
             u64 kept = 0ull;
             while (m) {
                 const int i = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
                 kept |= 1ull << i;
-                const float ix1 = __shfl(bx.x, i), iy1 = __shfl(bx.y, i), ix2 = __shfl(bx.z, i), iy2 = __shfl(bx.w, i);
-                const float ia = __shfl(ar, i);
-                const bool sup = (lane > i) && iou_gt(ix1, iy1, ix2, iy2, ia, bx.x, bx.y, bx.z, bx.w, ar, p.iou_thr);
-                m &= ~__ballot(sup);
+                m &= m - 1ull;
+                const u64 c = ((u64)(u32)__builtin_amdgcn_readlane(chi, i) << 32) | (u64)(u32)__builtin_amdgcn_readlane(clo, i);
+                m &= ~c;
             }
-            const u32 nk = (u32)__popcll(kept);
             if ((kept >> lane) & 1ull) {
                 const u32 pos = (u32)__popcll(kept & ((1ull << lane) - 1ull));
                 kb[pos] = bx;
                 ka[pos] = ar;
                 kseg[nkept + pos] = skey[j];
             }
-            if (lane == 0) *s_nk = nk;
+            if (lane == 0) *s_nk = (u32)__popcll(kept);
         }
         __syncthreads();
         const u32 nk = *s_nk;
         nkept += nk;
-        if (nk > 0) {
-            for (u32 j0 = (t + 1 + wave) * 64; j0 < n; j0 += 256) {
-                const u32 j = j0 + lane, w = j0 >> 6;
-                const bool todo = j < n && !((rem[w] >> lane) & 1ull);
+        // C: apply the tile's kept boxes to every later box, group by group
+        if (nk > 0 && t + 1 < ng) {
+            const u32 first_later = (t + 1) * 64;
+            float4 kx = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((u32)lane < nk) kx = kb[lane];
+            for (u32 g = wave; g < ng; g += 4) {
+                if (gmax[g] < first_later) continue;
+                const float4 bb = gbb[g];
+                const bool ov = (u32)lane < nk && kx.z > bb.x && kx.x < bb.z && kx.w > bb.y && kx.y < bb.w;
+                u64 rel = __ballot(ov);
+                if (rel == 0ull) continue;
+                const u32 s = g * 64 + lane;
+                const bool todo = s < n && mrank[s] >= first_later && !((rem[g] >> lane) & 1ull);
+                if (__ballot(todo) == 0ull) continue;
+                const float4 jx = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float ja = (jx.z - jx.x) * (jx.w - jx.y);
                 bool sup = false;
-                if (__ballot(todo)) {
-                    const float4 bx = (j < n) ? sbox[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float ar = (bx.z - bx.x) * (bx.w - bx.y);
-                    for (u32 k = 0; k < nk; ++k) {
-                        const float4 kx = kb[k];
-                        sup = sup || iou_gt(kx.x, kx.y, kx.z, kx.w, ka[k], bx.x, bx.y, bx.z, bx.w, ar, p.iou_thr);
-                    }
+                while (rel) {
+                    const int k = __ffsll((long long)rel) - 1;
+                    rel &= rel - 1ull;
+                    const float4 q = kb[k];
+                    sup = sup || iou_gt(q.x, q.y, q.z, q.w, ka[k], jx.x, jx.y, jx.z, jx.w, ja, p.iou_thr);
                 }
                 const u64 sm = __ballot(sup && todo);
-                if (lane == 0 && sm) rem[w] |= sm;
+                if (lane == 0 && sm) rem[g] |= sm;
             }
         }
         __syncthreads();
@@ -331,8 +438,30 @@ __global__ __launch_bounds__(256) void nms_gather_kernel(NmsParams p)
     }
 }
 
+__global__ void compact_scan_kernel(const int *counts, int batch, int max_out, long long *offsets)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        long long s = 0;
+        for (int b = 0; b < batch; ++b) {
+            offsets[b] = s;
+            s += min(counts[b], max_out);
+        }
+        offsets[batch] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void compact_copy_kernel(const float *rows, const int *counts, int max_out, int width,
+                                                           float *compact, const long long *offsets)
+{
+    const long long b = blockIdx.y;
+    const long long nfl = (long long)min(counts[b], max_out) * width;
+    const float *src = rows + b * max_out * width;
+    float *dst = compact + offsets[b] * width;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nfl; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
 struct WsLayout {
-    size_t tmp_key, tmp_meta, bkey, skey, kseg, sbox, counters, img_count, cls_count, kcnt, cls_off, total, counters_bytes;
+    size_t tmp_key, tmp_meta, bkey, skey, kseg, sbox, mbox, counters, img_count, cls_count, kcnt, cls_off, total, counters_bytes;
 };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -356,6 +485,7 @@ WsLayout ws_layout(int B, int A, int nc)
     L.skey = o; o += align_up(n * 8, 256);
     L.kseg = o; o += align_up(n * 8, 256);
     L.sbox = o; o += align_up(n * 16, 256);
+    L.mbox = o; o += align_up(n * 16, 256);
     L.total = o;
     return L;
 }
@@ -377,7 +507,6 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     const int nc = c - 5 - n_extra;
     YAMD_REQUIRE(batch > 0 && batch <= 65535 && a > 0 && n_extra >= 0 && nc > 0, "bad shape B=%d A=%d C=%d extra=%d", batch, a,
                  c, n_extra);
-    YAMD_REQUIRE(a <= (1 << 20), "A=%d exceeds the 2^20 anchors per image supported", a);
     YAMD_REQUIRE(max_out > 0, "max_out must be positive");
     // classes are swept independently; that equals the reference only while offset boxes of different
     // classes cannot intersect and IoU 0 never suppresses
@@ -391,13 +520,19 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     }
     const size_t flds = (size_t)FROWS * (c | 1) * 4 + (size_t)nc * 8 + 16;
     YAMD_REQUIRE(flds <= 150 * 1024, "C=%d too wide for the filter tile", c);
-    const size_t slds = (size_t)RANK_TILE * 8 + (size_t)((a + 63) / 64) * 8;
-    YAMD_REQUIRE(slds <= 150 * 1024, "A=%d too large for the sweep bitmask", a);
+    YAMD_REQUIRE(a <= 65536, "A=%d exceeds the 65536 anchors per image supported", a);
+    int sort_cap = 1;
+    while (sort_cap < a && sort_cap < 8192) sort_cap <<= 1;
+    const size_t ngmax = (size_t)(a + 63) / 64;
+    const size_t sweep_lds = ngmax * (16 + 8 + 4) + 64 * (16 + 8 + 4) + 16;
+    const size_t sort_lds = (size_t)sort_cap * 8;
+    const size_t slds = sort_lds > sweep_lds ? sort_lds : sweep_lds;
     char *ws = (char *)workspace;
     NmsParams p;
     p.pred = pred;
     p.B = batch; p.A = a; p.C = c; p.in_cxcywh = in_cxcywh ? 1 : 0; p.n_extra = n_extra; p.nc = nc;
     p.W = 7 + n_extra;
+    p.sort_cap = sort_cap;
     p.max_out = max_out;
     p.hi = img_size - 1.0f;
     p.conf_thr = conf_thr;
@@ -410,6 +545,11 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     p.skey = (u64 *)(ws + L.skey);
     p.kseg = (u64 *)(ws + L.kseg);
     p.sbox = (float4 *)(ws + L.sbox);
+    p.mbox = (float4 *)(ws + L.mbox);
+    // the unordered candidate lists are dead once the buckets are filled: their space holds the sweep's
+    // Morton-order rank / position tables (4 bytes per candidate each)
+    p.mrank = (u32 *)(ws + L.tmp_key);
+    p.posr = (u32 *)(ws + L.tmp_meta);
     p.img_count = (u32 *)(ws + L.img_count);
     p.cls_count = (u32 *)(ws + L.cls_count);
     p.kcnt = (u32 *)(ws + L.kcnt);
@@ -436,6 +576,21 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     hipLaunchKernelGGL(nms_segment_kernel, dim3(nc, batch), dim3(256), slds, st, p);
     YAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_gather_kernel, dim3(nc, batch), dim3(256), 0, st, p);
+    YAMD_LAUNCH_CHECK();
+    return YAMD_OK;
+}
+
+extern "C" int yamd_compact_rows(const float *rows, const int *counts, int batch, int max_out, int width, float *compact,
+                                 long long *offsets, void *stream)
+{
+    YAMD_REQUIRE(rows && counts && compact && offsets, "null argument");
+    YAMD_REQUIRE(batch > 0 && batch <= 65535 && max_out > 0 && width > 0, "bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(64), 0, st, counts, batch, max_out, offsets);
+    YAMD_LAUNCH_CHECK();
+    const int gx = ceil_div((long long)max_out * width, 256 * 8);
+    hipLaunchKernelGGL(compact_copy_kernel, dim3(gx > 64 ? 64 : gx, batch), dim3(256), 0, st, rows, counts, max_out, width,
+                       compact, offsets);
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
 }

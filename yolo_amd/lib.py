@@ -19,7 +19,7 @@ DECODE_V5, DECODE_V3, DECODE_POSE, DECODE_FACE = 0, 1, 2, 3
 EXPORTS = [
     "yamd_last_error", "yamd_version", "yamd_conv_desc_init", "yamd_conv_pack_weights", "yamd_conv2d_bias_act",
     "yamd_focus_pack", "yamd_nchw_to_nhwc16", "yamd_upsample2x", "yamd_maxpool5_cascade", "yamd_copy_channels",
-    "yamd_decode_anchor", "yamd_decode_dfl", "yamd_nms_workspace_bytes", "yamd_nms_batched",
+    "yamd_decode_anchor", "yamd_decode_dfl", "yamd_nms_workspace_bytes", "yamd_nms_batched", "yamd_compact_rows",
 ]
 
 
@@ -65,6 +65,7 @@ def _load() -> ctypes.CDLL:
     lib.yamd_nms_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.yamd_nms_batched.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_double, c_void_p,
                                      c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.yamd_compact_rows.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("yamd_last_error", "yamd_nms_workspace_bytes"):

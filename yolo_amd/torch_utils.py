@@ -8,6 +8,7 @@ the counts.  ``fuse_conv_and_bn`` is the host-side BatchNorm folding used when a
 import ctypes
 from typing import List, Optional, Tuple, Union
 
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -53,6 +54,19 @@ def nms_batched(prediction: torch.Tensor, img_size: float, in_fmt: str, conf_thr
                                     None if index is None else index.data_ptr(), max_out, counts.data_ptr(),
                                     ws.data_ptr(), ws.numel(), _lib.current_stream()), "nms_batched")
     return rows, counts, index
+
+
+def rows_to_host(rows: torch.Tensor, counts: torch.Tensor) -> List[Optional["np.ndarray"]]:
+    """Kept rows of the whole batch -> the reference's per-image list of ndarrays (None when empty) with
+    ONE packed device->host copy (plus the (B+1)-entry offset table) instead of one copy per image."""
+    B, max_out, W = rows.shape
+    compact = torch.empty((B * max_out, W), dtype=torch.float32, device=rows.device)
+    offsets = torch.empty((B + 1,), dtype=torch.int64, device=rows.device)
+    _lib.check(LIB.yamd_compact_rows(rows.data_ptr(), counts.data_ptr(), B, max_out, W, compact.data_ptr(),
+                                     offsets.data_ptr(), _lib.current_stream()), "compact_rows")
+    off = offsets.cpu().tolist()
+    host = compact[:off[-1]].cpu().numpy()
+    return [None if off[b + 1] == off[b] else host[off[b]:off[b + 1]] for b in range(B)]
 
 
 def _split(rows: torch.Tensor, counts: torch.Tensor) -> List[Optional[torch.Tensor]]:

@@ -218,10 +218,7 @@ class YoloV5(nn.Module):
                                                 _lib.DECODE_V5)
         rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "cxcywh", self.param.conf_threshold,
                                                   self.param.nms_threshold)
-        host_counts = counts.cpu().tolist()
-        kmax = max(host_counts) if host_counts else 0
-        host_rows = rows[:, :max(kmax, 1)].cpu().numpy()          # one compacted D2H for the batch
-        tensor_dict["predicts"] = [None if k == 0 else host_rows[b, :k].copy() for b, k in enumerate(host_counts)]
+        tensor_dict["predicts"] = torch_utils.rows_to_host(rows, counts)     # one packed D2H for the batch
         return tensor_dict
 
     def fuse(self) -> None:
