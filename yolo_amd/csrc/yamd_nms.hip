@@ -27,6 +27,7 @@
 #include "yamd_common.h"
 
 #include <cmath>
+#include <cstdlib>
 
 using namespace yamd;
 
@@ -42,7 +43,7 @@ struct NmsParams {
     u64 *tmp_key, *tmp_meta, *bkey, *skey, *kseg;
     float4 *sbox, *mbox;
     u32 *mrank, *posr;
-    int sort_cap;
+    int sort_cap, dbg;
     u32 *img_count, *cls_count, *cls_off, *kcnt;
     float *out_rows;
     int *out_index, *out_counts;
@@ -81,6 +82,7 @@ __device__ __forceinline__ void row_best(const float *cls, int nc, float &best, 
 }
 
 constexpr int FROWS = 256;
+constexpr int REGQ = 32;   // groups per wave whose boxes are kept in registers during the NMS sweep
 
 __global__ __launch_bounds__(256) void nms_filter_kernel(NmsParams p)
 {
@@ -237,8 +239,10 @@ __device__ __forceinline__ float rl(float v, int lane) { return __uint_as_float(
 __global__ __launch_bounds__(256) void nms_segment_kernel(NmsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_seg[];
-    const int cls = blockIdx.x;
-    const long long b = blockIdx.y;
+    // image index fastest: workgroups are dealt round-robin over the 8 XCDs in linear block order, and the
+    // heavy buckets are those of a few classes, so consecutive blocks must be different images of one class
+    const int cls = blockIdx.y;
+    const long long b = blockIdx.x;
     const u32 n = p.cls_count[b * p.nc + cls];
     if (n == 0) return;
     const u32 off = p.cls_off[b * (p.nc + 1) + cls];
@@ -285,6 +289,7 @@ __global__ __launch_bounds__(256) void nms_segment_kernel(NmsParams p)
     }
     __syncthreads();
 
+    if (p.dbg & 1) { if (tid == 0) p.kcnt[b * p.nc + cls] = 0; return; }
     // ---- sweep state in LDS (aliases the sort array)
     const u32 ng = (n + 63) / 64;                       // groups == tiles == mask words
     float4 *gbb = (float4 *)smem_seg;                   // ng group bounding boxes
@@ -316,6 +321,18 @@ __global__ __launch_bounds__(256) void nms_segment_kernel(NmsParams p)
     }
     __syncthreads();
 
+    // Boxes of this wave's groups (g = wave + 4q) stay in registers for the whole sweep when the bucket
+    // has at most 64*4*REGQ boxes; phase C then touches no global memory at all.
+    const bool use_regs = ng <= 4 * REGQ;
+    float4 rb[REGQ];
+    if (use_regs) {
+#pragma unroll
+        for (int q = 0; q < REGQ; ++q) {
+            const u32 s = (wave + 4 * q) * 64 + lane;
+            rb[q] = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
     u32 nkept = 0;
     for (u32 t = 0; t < ng; ++t) {
         // A: column i of the tile's suppression matrix = lanes j > i that box i would remove
@@ -330,7 +347,7 @@ __global__ __launch_bounds__(256) void nms_segment_kernel(NmsParams p)
         }
         const u32 tn = min(64u, n - t * 64);
 #pragma unroll 4
-        for (int ii = 0; ii < 16; ++ii) {
+        for (int ii = 0; ii < ((p.dbg & 4) ? 0 : 16); ++ii) {
             const int i = wave * 16 + ii;
             if ((u32)i >= tn) break;
             const float ix1 = rl(bx.x, i), iy1 = rl(bx.y, i), ix2 = rl(bx.z, i), iy2 = rl(bx.w, i), ia = rl(ar, i);
@@ -359,15 +376,44 @@ __global__ __launch_bounds__(256) void nms_segment_kernel(NmsParams p)
                 kseg[nkept + pos] = skey[j];
             }
             if (lane == 0) *s_nk = (u32)__popcll(kept);
+            // every box of this tile is decided now: flag it so that later phases skip it
+            if (inr) {
+                const u32 sp = posr[j];
+                atomicOr(&rem[sp >> 6], 1ull << (sp & 63));
+            }
         }
         __syncthreads();
         const u32 nk = *s_nk;
         nkept += nk;
         // C: apply the tile's kept boxes to every later box, group by group
-        if (nk > 0 && t + 1 < ng) {
+        if (nk > 0 && t + 1 < ng && !(p.dbg & 2)) {
             const u32 first_later = (t + 1) * 64;
             float4 kx = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((u32)lane < nk) kx = kb[lane];
+            if (use_regs) {
+#pragma unroll
+                for (int q = 0; q < REGQ; ++q) {
+                    const u32 g = wave + 4 * q;
+                    if (g >= ng || gmax[g] < first_later) continue;
+                    const float4 bb = gbb[g];
+                    const bool ov = (u32)lane < nk && kx.z > bb.x && kx.x < bb.z && kx.w > bb.y && kx.y < bb.w;
+                    u64 rel = __ballot(ov);
+                    if (rel == 0ull) continue;
+                    const bool todo = g * 64 + lane < n && !((rem[g] >> lane) & 1ull);
+                    if (__ballot(todo) == 0ull) continue;
+                    const float4 jx = rb[q];
+                    const float ja = (jx.z - jx.x) * (jx.w - jx.y);
+                    bool sup = false;
+                    while (rel) {
+                        const int k = __ffsll((long long)rel) - 1;
+                        rel &= rel - 1ull;
+                        const float4 qb = kb[k];
+                        sup = sup || iou_gt(qb.x, qb.y, qb.z, qb.w, ka[k], jx.x, jx.y, jx.z, jx.w, ja, p.iou_thr);
+                    }
+                    const u64 sm = __ballot(sup && todo);
+                    if (lane == 0 && sm) atomicOr(&rem[g], sm);
+                }
+            } else
             for (u32 g = wave; g < ng; g += 4) {
                 if (gmax[g] < first_later) continue;
                 const float4 bb = gbb[g];
@@ -387,7 +433,7 @@ __global__ __launch_bounds__(256) void nms_segment_kernel(NmsParams p)
                     sup = sup || iou_gt(q.x, q.y, q.z, q.w, ka[k], jx.x, jx.y, jx.z, jx.w, ja, p.iou_thr);
                 }
                 const u64 sm = __ballot(sup && todo);
-                if (lane == 0 && sm) rem[g] |= sm;
+                if (lane == 0 && sm) atomicOr(&rem[g], sm);
             }
         }
         __syncthreads();
@@ -398,8 +444,8 @@ __global__ __launch_bounds__(256) void nms_segment_kernel(NmsParams p)
 // kept rows of class `cls`: global rank = own position + number of larger keys in every other class
 __global__ __launch_bounds__(256) void nms_gather_kernel(NmsParams p)
 {
-    const int cls = blockIdx.x;
-    const long long b = blockIdx.y;
+    const int cls = blockIdx.y;
+    const long long b = blockIdx.x;
     const u32 *kcnt = p.kcnt + b * p.nc;
     const u32 *coff = p.cls_off + b * (p.nc + 1);
     if (cls == 0 && threadIdx.x == 0) {
@@ -505,7 +551,7 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
 {
     YAMD_REQUIRE(pred && out_rows && out_counts && workspace, "null argument");
     const int nc = c - 5 - n_extra;
-    YAMD_REQUIRE(batch > 0 && batch <= 65535 && a > 0 && n_extra >= 0 && nc > 0, "bad shape B=%d A=%d C=%d extra=%d", batch, a,
+    YAMD_REQUIRE(batch > 0 && a > 0 && n_extra >= 0 && nc > 0 && nc <= 65535 && batch <= 65535, "bad shape B=%d A=%d C=%d extra=%d", batch, a,
                  c, n_extra);
     YAMD_REQUIRE(max_out > 0, "max_out must be positive");
     // classes are swept independently; that equals the reference only while offset boxes of different
@@ -533,6 +579,7 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     p.B = batch; p.A = a; p.C = c; p.in_cxcywh = in_cxcywh ? 1 : 0; p.n_extra = n_extra; p.nc = nc;
     p.W = 7 + n_extra;
     p.sort_cap = sort_cap;
+    { const char *e = getenv("YAMD_NMS_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.max_out = max_out;
     p.hi = img_size - 1.0f;
     p.conf_thr = conf_thr;
@@ -573,9 +620,9 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     YAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_bucket_kernel, dim3(achunks, batch), dim3(256), 0, st, p);
     YAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_segment_kernel, dim3(nc, batch), dim3(256), slds, st, p);
+    hipLaunchKernelGGL(nms_segment_kernel, dim3(batch, nc), dim3(256), slds, st, p);
     YAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_gather_kernel, dim3(nc, batch), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(nms_gather_kernel, dim3(batch, nc), dim3(256), 0, st, p);
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
 }
