@@ -21,8 +21,11 @@
 #include <cstring>
 #include <cmath>
 #include <mutex>
+#include <type_traits>
 
 using namespace yamd;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -53,6 +56,29 @@ __device__ __forceinline__ float apply_act(float v, int act)
         return fmaxf(v, 0.0f);
     default:
         return v;
+    }
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>); every array index
+// inside f is a constant, so staging arrays stay in registers
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// activation of 4 values with ONE branch on the (uniform) kind
+__device__ __forceinline__ void act4(float (&v)[4], int act)
+{
+    if (act == YAMD_ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + __expf(-v[j]));
+    } else if (act != YAMD_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], act);
     }
 }
 
@@ -103,41 +129,59 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
+    // Staging registers: the next chunk's global loads are issued before the current chunk is computed
+    // and written to LDS afterwards, so HBM/L2 latency hides under the MFMA work.
+    constexpr int THMAX = (128 * MREP) / TW;
+    constexpr int NPHMAX = (THMAX - 1) * S + KS;
+    constexpr int AP = (NPHMAX * NPW * G8 + 255) / 256;   // activation pieces per thread
+    constexpr int WP = (WBYTES / 16 + 255) / 256;         // weight pieces per thread
+    u32x4 ra[AP], rw[WP];
     const int total = NPH * NPW * G8;
-    for (int ch = 0; ch < p.nchunks; ++ch) {
-        const int c0 = ch * CK;
-        __syncthreads();   // every wave is done reading the previous chunk
-        {
-            const char *wsrc = p.w + (size_t)(nt * p.nchunks + ch) * WBYTES;
-            for (int q = tid; q < WBYTES / 16; q += 256)
-                *(uint4 *)(ldsW + q * 16) = *(const uint4 *)(wsrc + q * 16);
-        }
-        for (int q0 = tid; q0 < total; q0 += 256 * 4) {
-            uint4 v[4];
-            int dst[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = q0 + u * 256;
-                v[u] = make_uint4(0u, 0u, 0u, 0u);
-                dst[u] = -1;
-                if (q < total) {
-                    const int pix = q / G8, gc = q % G8;
-                    const int hr = pix / NPW, hc = pix % NPW;
-                    const int ih = oh0 * S - PAD + hr, iw = ow0 * S - PAD + hc;
-                    const int lc = (S == 2) ? ((hc & 1) * NPWH + (hc >> 1)) : hc;
-                    dst[u] = (hr * NPW + lc) * RS + gc * 16;
-                    if (ih >= 0 && ih < p.H && iw >= 0 && iw < p.W) {
-                        const __bf16 *src = p.x + ((size_t)(b * p.H + ih) * p.W + iw) * p.x_cs + c0 + gc * 8;
-                        v[u] = *(const uint4 *)src;
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (dst[u] >= 0) *(uint4 *)(ldsA + dst[u]) = v[u];
-        }
-        __syncthreads();
 
+    // No divergent control flow in the staging: piece indices beyond the end are clamped (the duplicate
+    // loads/stores are benign) and out-of-image pixels load a clamped address and are zeroed by a select.
+    auto issue_loads = [&](int ch) __attribute__((always_inline)) {
+        const int c0 = ch * CK;
+        const char *wsrc = p.w + (size_t)(nt * p.nchunks + ch) * WBYTES;
+        static_for<WP>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            const int q = min(tid + u * 256, WBYTES / 16 - 1);
+            rw[u] = *(const u32x4 *)(wsrc + q * 16);
+        });
+        static_for<AP>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            const int q = min(tid + u * 256, total - 1);
+            const int pix = q / G8, gc = q % G8;
+            const int hr = pix / NPW, hc = pix % NPW;
+            const int ih = oh0 * S - PAD + hr, iw = ow0 * S - PAD + hc;
+            const bool inb = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
+            const u32x4 v = *(const u32x4 *)(p.x + ((size_t)(b * p.H + ihc) * p.W + iwc) * p.x_cs + c0 + gc * 8);
+            ra[u] = inb ? v : u32x4{0u, 0u, 0u, 0u};
+        });
+    };
+    auto write_lds = [&]() __attribute__((always_inline)) {
+        static_for<WP>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            const int q = min(tid + u * 256, WBYTES / 16 - 1);
+            *(u32x4 *)(ldsW + q * 16) = rw[u];
+        });
+        static_for<AP>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            const int q = min(tid + u * 256, total - 1);
+            const int pix = q / G8, gc = q % G8;
+            const int hr = pix / NPW, hc = pix % NPW;
+            const int lc = (S == 2) ? ((hc & 1) * NPWH + (hc >> 1)) : hc;
+            *(u32x4 *)(ldsA + (hr * NPW + lc) * RS + gc * 16) = ra[u];
+        });
+    };
+
+    issue_loads(0);
+    write_lds();
+    __syncthreads();
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        const bool more = ch + 1 < p.nchunks;
+        if (more) issue_loads(ch + 1);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int kh = tap / KS, kw = tap % KS;
@@ -157,32 +201,59 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[n], a[m], acc[m][n], 0, 0, 0);
             }
         }
+        __syncthreads();   // every wave is done reading this chunk
+        if (more) {
+            write_lds();
+            __syncthreads();
+        }
     }
 
     // epilogue: lane holds, for pixel c32 of each fragment, couts 8*i + 4*g + j (i,j = 0..3)
+    if constexpr (OUT_F32) {
 #pragma unroll
-    for (int m = 0; m < MREP; ++m) {
-        const int pp = wave * (32 * MREP) + m * 32 + c32;
-        const int pr = pp / TW, pc = pp % TW;
-        const int oh = oh0 + pr, ow = ow0 + pc;
-        const bool valid = pr < p.TH && oh < p.Hout && ow < p.Wout;
-        const size_t pix = (size_t)(b * p.Hout + oh) * p.Wout + ow;
+        for (int m = 0; m < MREP; ++m) {
+            const int pp = wave * (32 * MREP) + m * 32 + c32;
+            const int pr = pp / TW, pc = pp % TW;
+            const int oh = oh0 + pr, ow = ow0 + pc;
+            const bool valid = pr < p.TH && oh < p.Hout && ow < p.Wout;
+            const size_t pix = (size_t)(b * p.Hout + oh) * p.Wout + ow;
 #pragma unroll
-        for (int n = 0; n < NREP; ++n) {
+            for (int n = 0; n < NREP; ++n) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int co = nt * (NREP * 32) + n * 32 + 8 * i + 4 * g;
-                if (!valid || co >= p.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = apply_act(acc[m][n][4 * i + j] + p.bias[co + j], p.act);
-                if constexpr (OUT_F32) {
+                for (int i = 0; i < 4; ++i) {
+                    const int co = nt * (NREP * 32) + n * 32 + 8 * i + 4 * g;
+                    if (!valid || co >= p.Cout) continue;
                     float *y = (float *)p.y + pix * p.y_cs + co;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (co + j < p.Cout) y[j] = v[j];
-                } else {
-                    if (p.res) {
+                        if (co + j < p.Cout) y[j] = apply_act(acc[m][n][4 * i + j] + p.bias[co + j], p.act);
+                }
+            }
+        }
+    } else {
+        // bf16 output goes through a per-wave LDS tile [32 pixels][BN couts] so that the global stores are
+        // 16 bytes per lane and whole pixel rows (BN*2 contiguous bytes) per group of lanes.
+        constexpr int RSO = NREP * 64 + 16;        // bytes per pixel row of the staging tile
+        constexpr int PPR = NREP * 4;              // 16-byte pieces per pixel
+        constexpr int PIXPI = 64 / PPR;            // pixels per wave store instruction
+        char *wreg = smem + wave * (32 * RSO);     // the chunk loop ended with a barrier: LDS is free
+        auto epilogue = [&](auto mc) __attribute__((always_inline)) {
+            constexpr int m = decltype(mc)::value;
+            const int pp = wave * (32 * MREP) + m * 32 + c32;
+            const int pr = pp / TW, pc = pp % TW;
+            const bool valid = pr < p.TH && oh0 + pr < p.Hout && ow0 + pc < p.Wout;
+            const size_t pix = (size_t)(b * p.Hout + oh0 + pr) * p.Wout + ow0 + pc;
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cl = n * 32 + 8 * i + 4 * g;
+                    const int co = nt * (NREP * 32) + cl;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[m][n][4 * i + j] + p.bias[co + j];
+                    act4(v, p.act);
+                    if (p.res && valid && co < p.Cout) {
                         const bf16x4 r = *(const bf16x4 *)(p.res + pix * p.res_cs + co);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
@@ -190,10 +261,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
                     bf16x4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
-                    *(bf16x4 *)((__bf16 *)p.y + pix * p.y_cs + co) = o;
+                    *(bf16x4 *)(wreg + c32 * RSO + cl * 2) = o;
                 }
             }
-        }
+            // the tile is private to this wave: order the LDS writes before the cross-lane reads
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 32 / PIXPI; ++it) {
+                const int r = it * PIXPI + lane / PPR, piece = lane % PPR;
+                const uint4 v = *(const uint4 *)(wreg + r * RSO + piece * 16);
+                const int pq = wave * (32 * MREP) + m * 32 + r;
+                const int qr = pq / TW, qc = pq % TW;
+                const int co = nt * (NREP * 32) + piece * 8;
+                if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout && co < p.Cout)
+                    *(uint4 *)((__bf16 *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + co) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        };
+        epilogue(std::integral_constant<int, 0>{});
+        if constexpr (MREP > 1) epilogue(std::integral_constant<int, 1>{});
     }
 }
 
@@ -204,7 +292,8 @@ int launch_conv(const ConvParams &p, int batch, hipStream_t stream)
     constexpr int RS = CK * 2 + 16;
     constexpr int WBYTES = KS * KS * (CK / 16) * NREP * 1024;
     const int NPH = (p.TH - 1) * S + KS;
-    const size_t lds = (size_t)WBYTES + (size_t)NPH * NPW * RS;
+    size_t lds = (size_t)WBYTES + (size_t)NPH * NPW * RS;
+    if (!OUT_F32 && lds < (size_t)4 * 32 * (NREP * 64 + 16)) lds = (size_t)4 * 32 * (NREP * 64 + 16);
     YAMD_REQUIRE(lds <= 160 * 1024, "conv tile needs %zu bytes of LDS", lds);
     auto kern = conv_igemm_kernel<KS, S, TW, MREP, NREP, CK, OUT_F32>;
     static std::once_flag once;
@@ -328,8 +417,8 @@ extern "C" int yamd_conv2d_bias_act(const yamd_conv_desc *d, const void *x, int 
                  "input needs 16-byte aligned pixels (cstride=%d)", x_cstride);
     YAMD_REQUIRE(((uintptr_t)w_packed % 16) == 0, "packed weights must be 16-byte aligned");
     if (!d->out_f32) {
-        YAMD_REQUIRE(y_cstride >= d->cout && y_cstride % 4 == 0 && ((uintptr_t)y % 8) == 0,
-                     "bf16 output needs 8-byte aligned pixels (cstride=%d)", y_cstride);
+        YAMD_REQUIRE(y_cstride >= d->cout && y_cstride % 8 == 0 && ((uintptr_t)y % 16) == 0,
+                     "bf16 output needs 16-byte aligned pixels (cstride=%d)", y_cstride);
         if (residual)
             YAMD_REQUIRE(res_cstride >= d->cout && res_cstride % 4 == 0 && ((uintptr_t)residual % 8) == 0,
                          "residual needs 8-byte aligned pixels (cstride=%d)", res_cstride);
