@@ -82,7 +82,7 @@ __device__ __forceinline__ void row_best(const float *cls, int nc, float &best, 
 }
 
 constexpr int FROWS = 256;
-constexpr int REGQ = 32;   // groups per wave whose boxes are kept in registers during the NMS sweep
+constexpr int REGQ = 8;   // groups per wave whose boxes are kept in registers during the NMS sweep
 
 __global__ __launch_bounds__(256) void nms_filter_kernel(NmsParams p)
 {
@@ -178,7 +178,10 @@ __device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy
     return ovr > thr;
 }
 
-// In-place bitonic sort, descending, of n (any n) 64-bit keys by one 256-thread workgroup.  `a` may
+constexpr int SEG_THREADS = 1024;           // 16 waves per bucket
+constexpr int SEG_WAVES = SEG_THREADS / 64;
+
+// In-place bitonic sort, descending, of n (any n) 64-bit keys by one SEG_THREADS workgroup.  `a` may
 // point to LDS or to global memory.  The network only uses comparators that move the larger key to the
 // lower index (each merge starts with a mirror step), so the virtual padding "smaller than everything"
 // beyond n never has to move and needs no storage.
@@ -189,7 +192,7 @@ __device__ void bitonic_sort_desc(u64 *a, u32 n, int tid)
     const u32 half = npad >> 1;
     for (u32 k = 2; k <= npad; k <<= 1) {
         const u32 h = k >> 1;
-        for (u32 c = tid; c < half; c += 256) {
+        for (u32 c = tid; c < half; c += SEG_THREADS) {
             const u32 i = ((c & ~(h - 1)) << 1) | (c & (h - 1));
             const u32 l = i ^ (k - 1);
             if (l < n) {
@@ -199,7 +202,7 @@ __device__ void bitonic_sort_desc(u64 *a, u32 n, int tid)
         }
         __syncthreads();
         for (u32 j = k >> 2; j > 0; j >>= 1) {
-            for (u32 c = tid; c < half; c += 256) {
+            for (u32 c = tid; c < half; c += SEG_THREADS) {
                 const u32 i = ((c & ~(j - 1)) << 1) | (c & (j - 1));
                 const u32 l = i | j;
                 if (l < n) {
@@ -224,19 +227,21 @@ __device__ __forceinline__ u32 spread10(u32 v)   // 10 bits -> every second bit
 
 __device__ __forceinline__ float rl(float v, int lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
 
-// One workgroup per (class, image) bucket.
+// One 16-wave workgroup per (class, image) bucket.
 //  1. sort the bucket's keys (descending = the stable descending score order),
 //  2. write keys / class-offset boxes in that order, then order the same boxes along a Morton curve of
 //     their centres so that 64 consecutive boxes form a spatially compact GROUP with a small bounding box,
-//  3. greedy sweep in tiles of 64 score-consecutive boxes:
-//       A  all four waves compute the tile's 64x64 suppression matrix as 64 ballots (columns),
-//       B  wave 0 resolves the tile serially on scalar bit masks,
-//       C  every wave takes groups; the tile's kept boxes (one per lane) are first tested against the
-//          group's bounding box with one ballot, and only the few that can intersect it are applied to
-//          the group's boxes; results land in the removed-bitmask (one 64-bit word per group).
+//  3. greedy sweep in tiles of 64 score-consecutive boxes, two barriers per tile:
+//       B(t)  wave 0 resolves tile t serially on scalar bit masks from the tile's 64x64 suppression matrix
+//             (64 column ballots in LDS) and the removed-bits; the kept boxes go to LDS;
+//       C(t)  every wave takes groups; the kept boxes (one per lane) are first tested against the group's
+//             bounding box with one ballot, and only the few that can intersect it are applied to the
+//             group's boxes (held in registers); results land in the removed-bitmask (one 64-bit word per
+//             group);
+//       A(t+1) in the same interval every wave computes 4 columns of the next tile's suppression matrix.
 //     The bounding-box test only skips pairs whose intersection is exactly empty, so the kept set is
 //     the one the plain greedy loop produces.
-__global__ __launch_bounds__(256) void nms_segment_kernel(NmsParams p)
+__global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_seg[];
     // image index fastest: workgroups are dealt round-robin over the 8 XCDs in linear block order, and the
@@ -261,14 +266,14 @@ __global__ __launch_bounds__(256) void nms_segment_kernel(NmsParams p)
     // ---- 1. sort by key: in LDS when the bucket fits, else in place in global memory (skey)
     const bool in_lds = n <= (u32)p.sort_cap;
     u64 *S = in_lds ? (u64 *)smem_seg : skey;
-    for (u32 i = tid; i < n; i += 256) S[i] = keys[i];
+    for (u32 i = tid; i < n; i += SEG_THREADS) S[i] = keys[i];
     __syncthreads();
     bitonic_sort_desc(S, n, tid);
 
     // ---- 2. sorted keys + offset boxes out; Morton keys in
     u64 *M = in_lds ? (u64 *)smem_seg : kseg;       // kseg is free until the sweep writes kept keys
     const float qs = 1024.0f / (p.hi + 1.0f);
-    for (u32 r = tid; r < n; r += 256) {
+    for (u32 r = tid; r < n; r += SEG_THREADS) {
         const u64 key = S[r];
         const u32 idx = 0xFFFFFFFFu - (u32)key;
         float x1, y1, x2, y2;
@@ -281,25 +286,25 @@ __global__ __launch_bounds__(256) void nms_segment_kernel(NmsParams p)
     }
     __syncthreads();
     bitonic_sort_desc(M, n, tid);
-    for (u32 s = tid; s < n; s += 256) {
+    for (u32 s = tid; s < n; s += SEG_THREADS) {
         const u32 r = (u32)M[s];
         mrank[s] = r;
         posr[r] = s;
         mbox[s] = sbox[r];
     }
     __syncthreads();
-
     if (p.dbg & 1) { if (tid == 0) p.kcnt[b * p.nc + cls] = 0; return; }
+
     // ---- sweep state in LDS (aliases the sort array)
     const u32 ng = (n + 63) / 64;                       // groups == tiles == mask words
     float4 *gbb = (float4 *)smem_seg;                   // ng group bounding boxes
     float4 *kb = gbb + ng;                              // 64 kept boxes of the current tile
-    u64 *rem = (u64 *)(kb + 64);                        // ng removed-bit words (by Morton position)
+    u64 *rem = (u64 *)(kb + 64);                        // ng removed/decided-bit words (by Morton position)
     u64 *colmask = rem + ng;                            // 64
     u32 *gmax = (u32 *)(colmask + 64);                  // ng: largest score rank inside the group
     float *ka = (float *)(gmax + ng);                   // 64 areas
     u32 *s_nk = (u32 *)(ka + 64);
-    for (u32 g = wave; g < ng; g += 4) {
+    for (u32 g = wave; g < ng; g += SEG_WAVES) {
         const u32 s = g * 64 + lane;
         const bool v = s < n;
         const float4 bx = v ? mbox[s] : make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
@@ -319,81 +324,101 @@ __global__ __launch_bounds__(256) void nms_segment_kernel(NmsParams p)
             rem[g] = 0ull;
         }
     }
-    __syncthreads();
 
-    // Boxes of this wave's groups (g = wave + 4q) stay in registers for the whole sweep when the bucket
-    // has at most 64*4*REGQ boxes; phase C then touches no global memory at all.
-    const bool use_regs = ng <= 4 * REGQ;
+    // Boxes of this wave's groups (g = wave + 16q) stay in registers for the whole sweep when the bucket
+    // has at most 64*16*REGQ boxes; phase C then touches no global memory at all.
+    const bool use_regs = ng <= (u32)(SEG_WAVES * REGQ);
     float4 rb[REGQ];
     if (use_regs) {
 #pragma unroll
         for (int q = 0; q < REGQ; ++q) {
-            const u32 s = (wave + 4 * q) * 64 + lane;
+            const u32 s = (wave + SEG_WAVES * q) * 64 + lane;
             rb[q] = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 
+    // columns [4*wave, 4*wave+4) of tile `t`'s suppression matrix: bit j of column i = box i removes box j > i
+    constexpr int CPW = 64 / SEG_WAVES;
+    auto phase_a = [&](u32 t, const float4 bx, const float ar) __attribute__((always_inline)) {
+        const u32 tn = min(64u, n - t * 64);
+        const bool inr = (u32)lane < tn;
+#pragma unroll
+        for (int ii = 0; ii < CPW; ++ii) {
+            const int i = wave * CPW + ii;
+            if ((u32)i < tn) {
+                const float ix1 = rl(bx.x, i), iy1 = rl(bx.y, i), ix2 = rl(bx.z, i), iy2 = rl(bx.w, i), ia = rl(ar, i);
+                const bool sup = inr && lane > i && iou_gt(ix1, iy1, ix2, iy2, ia, bx.x, bx.y, bx.z, bx.w, ar, p.iou_thr);
+                const u64 cm = __ballot(sup);
+                if (lane == 0) colmask[i] = cm;
+            }
+        }
+    };
+    auto tile_box = [&](u32 t) __attribute__((always_inline)) {
+        const u32 j = t * 64 + lane;
+        return j < n ? sbox[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+
+    float4 bx = tile_box(0);                            // this lane's box of the current tile (by score rank)
+    float ar = (bx.z - bx.x) * (bx.w - bx.y);
+    __syncthreads();                                    // gbb/gmax/rem complete
+    phase_a(0, bx, ar);
+    u32 sp_cur = lane < (int)min(64u, n) ? posr[lane] : 0u;   // Morton position of this lane's tile box
+    u64 key_cur = lane < (int)min(64u, n) ? skey[lane] : 0ull;
+    __syncthreads();
+
     u32 nkept = 0;
     for (u32 t = 0; t < ng; ++t) {
-        // A: column i of the tile's suppression matrix = lanes j > i that box i would remove
-        const u32 j = t * 64 + lane;
-        const bool inr = j < n;
-        const float4 bx = inr ? sbox[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float ar = (bx.z - bx.x) * (bx.w - bx.y);
-        bool alive = false;
-        if (wave == 0 && inr) {
-            const u32 sp = posr[j];
-            alive = !((rem[sp >> 6] >> (sp & 63)) & 1ull);
-        }
         const u32 tn = min(64u, n - t * 64);
-#pragma unroll 4
-        for (int ii = 0; ii < ((p.dbg & 4) ? 0 : 16); ++ii) {
-            const int i = wave * 16 + ii;
-            if ((u32)i >= tn) break;
-            const float ix1 = rl(bx.x, i), iy1 = rl(bx.y, i), ix2 = rl(bx.z, i), iy2 = rl(bx.w, i), ia = rl(ar, i);
-            const bool sup = inr && lane > i && iou_gt(ix1, iy1, ix2, iy2, ia, bx.x, bx.y, bx.z, bx.w, ar, p.iou_thr);
-            const u64 cm = __ballot(sup);
-            if (lane == 0) colmask[i] = cm;
-        }
-        __syncthreads();
-        // B: serial resolve on wave 0
+        // ---- B(t): serial resolve on wave 0
         if (wave == 0) {
-            const u64 mycol = (u32)lane < tn ? colmask[lane] : 0ull;
+            const bool inr = (u32)lane < tn;
+            const bool alive = inr && !((rem[sp_cur >> 6] >> (sp_cur & 63)) & 1ull);
+            const u64 mycol = inr ? colmask[lane] : 0ull;
             const u32 clo = (u32)mycol, chi = (u32)(mycol >> 32);
             u64 m = __ballot(alive);
-            u64 kept = 0ull;
-            while (m) {
-                const int i = __ffsll((long long)m) - 1;
-                kept |= 1ull << i;
-                m &= m - 1ull;
-                const u64 c = ((u64)(u32)__builtin_amdgcn_readlane(chi, i) << 32) | (u64)(u32)__builtin_amdgcn_readlane(clo, i);
-                m &= ~c;
+            u64 cand = m & __ballot(mycol != 0ull);     // only boxes that remove something need a serial step
+            while (cand) {
+                const int i = __ffsll((long long)cand) - 1;
+                cand &= cand - 1ull;
+                if ((m >> i) & 1ull) {
+                    const u64 c = ((u64)(u32)__builtin_amdgcn_readlane(chi, i) << 32) | (u64)(u32)__builtin_amdgcn_readlane(clo, i);
+                    m &= ~c;
+                }
             }
+            const u64 kept = m;
             if ((kept >> lane) & 1ull) {
                 const u32 pos = (u32)__popcll(kept & ((1ull << lane) - 1ull));
                 kb[pos] = bx;
                 ka[pos] = ar;
-                kseg[nkept + pos] = skey[j];
+                kseg[nkept + pos] = key_cur;
             }
             if (lane == 0) *s_nk = (u32)__popcll(kept);
             // every box of this tile is decided now: flag it so that later phases skip it
-            if (inr) {
-                const u32 sp = posr[j];
-                atomicOr(&rem[sp >> 6], 1ull << (sp & 63));
-            }
+            if (inr) atomicOr(&rem[sp_cur >> 6], 1ull << (sp_cur & 63));
         }
         __syncthreads();
         const u32 nk = *s_nk;
         nkept += nk;
-        // C: apply the tile's kept boxes to every later box, group by group
-        if (nk > 0 && t + 1 < ng && !(p.dbg & 2)) {
+        // ---- next tile's data first (latency hides under C), then C(t), then A(t+1)
+        const bool have_next = t + 1 < ng;
+        float4 nbx = make_float4(0.f, 0.f, 0.f, 0.f);
+        u32 nsp = 0;
+        u64 nkey = 0ull;
+        if (have_next) {
+            const u32 j = (t + 1) * 64 + lane;
+            if (j < n) {
+                nbx = sbox[j];
+                if (wave == 0) { nsp = posr[j]; nkey = skey[j]; }
+            }
+        }
+        if (nk > 0 && have_next && !(p.dbg & 2)) {
             const u32 first_later = (t + 1) * 64;
             float4 kx = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((u32)lane < nk) kx = kb[lane];
             if (use_regs) {
 #pragma unroll
                 for (int q = 0; q < REGQ; ++q) {
-                    const u32 g = wave + 4 * q;
+                    const u32 g = wave + SEG_WAVES * q;
                     if (g >= ng || gmax[g] < first_later) continue;
                     const float4 bb = gbb[g];
                     const bool ov = (u32)lane < nk && kx.z > bb.x && kx.x < bb.z && kx.w > bb.y && kx.y < bb.w;
@@ -413,28 +438,36 @@ __global__ __launch_bounds__(256) void nms_segment_kernel(NmsParams p)
                     const u64 sm = __ballot(sup && todo);
                     if (lane == 0 && sm) atomicOr(&rem[g], sm);
                 }
-            } else
-            for (u32 g = wave; g < ng; g += 4) {
-                if (gmax[g] < first_later) continue;
-                const float4 bb = gbb[g];
-                const bool ov = (u32)lane < nk && kx.z > bb.x && kx.x < bb.z && kx.w > bb.y && kx.y < bb.w;
-                u64 rel = __ballot(ov);
-                if (rel == 0ull) continue;
-                const u32 s = g * 64 + lane;
-                const bool todo = s < n && mrank[s] >= first_later && !((rem[g] >> lane) & 1ull);
-                if (__ballot(todo) == 0ull) continue;
-                const float4 jx = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float ja = (jx.z - jx.x) * (jx.w - jx.y);
-                bool sup = false;
-                while (rel) {
-                    const int k = __ffsll((long long)rel) - 1;
-                    rel &= rel - 1ull;
-                    const float4 q = kb[k];
-                    sup = sup || iou_gt(q.x, q.y, q.z, q.w, ka[k], jx.x, jx.y, jx.z, jx.w, ja, p.iou_thr);
+            } else {
+                for (u32 g = wave; g < ng; g += SEG_WAVES) {
+                    if (gmax[g] < first_later) continue;
+                    const float4 bb = gbb[g];
+                    const bool ov = (u32)lane < nk && kx.z > bb.x && kx.x < bb.z && kx.w > bb.y && kx.y < bb.w;
+                    u64 rel = __ballot(ov);
+                    if (rel == 0ull) continue;
+                    const u32 s = g * 64 + lane;
+                    const bool todo = s < n && !((rem[g] >> lane) & 1ull);
+                    if (__ballot(todo) == 0ull) continue;
+                    const float4 jx = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float ja = (jx.z - jx.x) * (jx.w - jx.y);
+                    bool sup = false;
+                    while (rel) {
+                        const int k = __ffsll((long long)rel) - 1;
+                        rel &= rel - 1ull;
+                        const float4 qb = kb[k];
+                        sup = sup || iou_gt(qb.x, qb.y, qb.z, qb.w, ka[k], jx.x, jx.y, jx.z, jx.w, ja, p.iou_thr);
+                    }
+                    const u64 sm = __ballot(sup && todo);
+                    if (lane == 0 && sm) atomicOr(&rem[g], sm);
                 }
-                const u64 sm = __ballot(sup && todo);
-                if (lane == 0 && sm) atomicOr(&rem[g], sm);
             }
+        }
+        if (have_next) {
+            bx = nbx;
+            ar = (bx.z - bx.x) * (bx.w - bx.y);
+            sp_cur = nsp;
+            key_cur = nkey;
+            phase_a(t + 1, bx, ar);
         }
         __syncthreads();
     }
@@ -620,7 +653,7 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     YAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_bucket_kernel, dim3(achunks, batch), dim3(256), 0, st, p);
     YAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_segment_kernel, dim3(batch, nc), dim3(256), slds, st, p);
+    hipLaunchKernelGGL(nms_segment_kernel, dim3(batch, nc), dim3(SEG_THREADS), slds, st, p);
     YAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_gather_kernel, dim3(batch, nc), dim3(256), 0, st, p);
     YAMD_LAUNCH_CHECK();
