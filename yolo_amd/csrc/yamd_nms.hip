@@ -474,35 +474,52 @@ __global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
     if (tid == 0) p.kcnt[b * p.nc + cls] = nkept;
 }
 
-// kept rows of class `cls`: global rank = own position + number of larger keys in every other class
-__global__ __launch_bounds__(256) void nms_gather_kernel(NmsParams p)
+// kept rows of class `cls`: global rank = own position + number of larger keys in every other class.
+// The other classes' kept lists (each already descending) are streamed through LDS in chunks and every
+// thread binary-searches its own key there.
+constexpr int GATHER_THREADS = 1024;
+constexpr int GATHER_CHUNK = 2048;
+__global__ __launch_bounds__(GATHER_THREADS) void nms_gather_kernel(NmsParams p)
 {
+    __shared__ u64 lk[GATHER_CHUNK];
     const int cls = blockIdx.y;
     const long long b = blockIdx.x;
     const u32 *kcnt = p.kcnt + b * p.nc;
     const u32 *coff = p.cls_off + b * (p.nc + 1);
-    if (cls == 0 && threadIdx.x == 0) {
+    const int tid = threadIdx.x;
+    if (cls == 0 && tid == 0) {
         u32 s = 0;
         for (int c = 0; c < p.nc; ++c) s += kcnt[c];
         p.out_counts[b] = (int)s;
     }
     const u32 mine = kcnt[cls];
+    if (mine == 0) return;
     const u64 *kbase = p.kseg + b * p.A;
-    for (u32 i = threadIdx.x; i < mine; i += 256) {
-        const u64 key = kbase[coff[cls] + i];
+    for (u32 i0 = 0; i0 < mine; i0 += GATHER_THREADS) {
+        const u32 i = i0 + tid;
+        const bool have = i < mine;
+        const u64 key = have ? kbase[coff[cls] + i] : 0ull;
         u32 rank = i;
         for (int c = 0; c < p.nc; ++c) {
             const u32 m = kcnt[c];
             if (c == cls || m == 0) continue;
-            const u64 *L = kbase + coff[c];   // descending
-            u32 lo = 0, hi = m;               // count of elements > key
-            while (lo < hi) {
-                const u32 mid = (lo + hi) >> 1;
-                if (L[mid] > key) lo = mid + 1; else hi = mid;
+            const u64 *L = kbase + coff[c];
+            for (u32 c0 = 0; c0 < m; c0 += GATHER_CHUNK) {
+                const u32 cn = min((u32)GATHER_CHUNK, m - c0);
+                __syncthreads();
+                for (u32 j = tid; j < cn; j += GATHER_THREADS) lk[j] = L[c0 + j];
+                __syncthreads();
+                if (have) {
+                    u32 lo = 0, hi = cn;               // count of elements > key (list is descending)
+                    while (lo < hi) {
+                        const u32 mid = (lo + hi) >> 1;
+                        if (lk[mid] > key) lo = mid + 1; else hi = mid;
+                    }
+                    rank += lo;
+                }
             }
-            rank += lo;
         }
-        if (rank >= (u32)p.max_out) continue;
+        if (!have || rank >= (u32)p.max_out) continue;
         const u32 idx = 0xFFFFFFFFu - (u32)key;
         const float *row = p.pred + (b * p.A + idx) * (long long)p.C;
         float *o = p.out_rows + (b * p.max_out + rank) * (long long)p.W;
@@ -655,7 +672,7 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     YAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_segment_kernel, dim3(batch, nc), dim3(SEG_THREADS), slds, st, p);
     YAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_gather_kernel, dim3(batch, nc), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(nms_gather_kernel, dim3(batch, nc), dim3(GATHER_THREADS), 0, st, p);
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
 }
