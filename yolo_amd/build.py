@@ -18,11 +18,15 @@ LIB = os.path.join(HERE, "libyolo_amd.so")
 SOURCES = [
     ("yamd_core.hip", []),
     ("yamd_conv.hip", []),
+    ("yamd_conv_k1.hip", []),
+    ("yamd_conv_k3s1.hip", []),
+    ("yamd_conv_k3s2.hip", []),
     ("yamd_decode.hip", ["-ffp-contract=off"]),
     ("yamd_nms.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
-HEADERS = [os.path.join(CSRC, "yamd_common.h"), os.path.join(HERE, "..", "include", "yolo_amd.h")]
+HEADERS = [os.path.join(CSRC, "yamd_common.h"), os.path.join(CSRC, "yamd_conv_kernel.h"),
+           os.path.join(HERE, "..", "include", "yolo_amd.h")]
 
 
 def _hipcc() -> str:
@@ -57,7 +61,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         subprocess.check_call(cmd)
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(7, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs)

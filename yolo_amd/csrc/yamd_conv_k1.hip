@@ -1,0 +1,23 @@
+// Instantiations of the implicit-GEMM conv kernel for one (kernel size, stride) family.
+#include "yamd_conv_kernel.h"
+
+namespace yamd {
+int conv_dispatch_k1(const ConvParams &p, int batch, int tw, int mrep, int nrep, int ck, int f32, hipStream_t st)
+{
+    if (mrep == 2 && nrep == 1 && ck == 32 && f32 == 0)
+        return launch_conv_variant<1, 1, 2, 1, 32, false>(p, batch, tw, st);
+    if (mrep == 2 && nrep == 2 && ck == 32 && f32 == 0)
+        return launch_conv_variant<1, 1, 2, 2, 32, false>(p, batch, tw, st);
+    if (mrep == 2 && nrep == 4 && ck == 32 && f32 == 0)
+        return launch_conv_variant<1, 1, 2, 4, 32, false>(p, batch, tw, st);
+    if (mrep == 2 && nrep == 1 && ck == 64 && f32 == 0)
+        return launch_conv_variant<1, 1, 2, 1, 64, false>(p, batch, tw, st);
+    if (mrep == 2 && nrep == 2 && ck == 64 && f32 == 0)
+        return launch_conv_variant<1, 1, 2, 2, 64, false>(p, batch, tw, st);
+    if (mrep == 2 && nrep == 4 && ck == 64 && f32 == 0)
+        return launch_conv_variant<1, 1, 2, 4, 64, false>(p, batch, tw, st);
+    if (mrep == 2 && nrep == 4 && ck == 64 && f32 == 1)
+        return launch_conv_variant<1, 1, 2, 4, 64, true>(p, batch, tw, st);
+    return 1;   // not built
+}
+}  // namespace yamd

@@ -1,0 +1,360 @@
+// Conv + bias (folded BatchNorm) + activation (+ residual) as an NHWC implicit GEMM on bf16 MFMA.
+//
+// GEMM view: D[cout][pixel] = sum_k W[cout][k] * X[pixel][k], k = (tap, cin).  A workgroup owns a
+// TH x TW spatial tile of output pixels (BM = 128*MREP slots) times BN = 32*NREP output channels.
+// Per input-channel chunk of CK channels it stages
+//   - the input halo tile ((TH-1)*S+KS) x ((TW-1)*S+KS) pixels x CK channels into LDS once
+//     (so a 3x3 conv reads HBM ~1.3x, not 9x), one padded row per halo pixel, and
+//   - the matching packed weight blob (all taps) with a linear copy,
+// then walks taps x 16-channel k-steps issuing v_mfma_f32_32x32x16_bf16 with the weights as the
+// A operand (rows = cout) and activations as the B operand (cols = pixel).  The fp32 accumulator
+// of a lane then holds 4 consecutive couts of one pixel per register quad, which is exactly an
+// 8-byte NHWC store.
+//
+// LDS image of the activations: halo pixel row stride RS = CK*2 + 16 bytes.  RS/16 is odd, and a
+// ds_read_b128 of the 32x32x16 operand serves 16 lanes of one k-group with 16 distinct pixels
+// (mod 16) per LDS cycle, so the fragment reads are bank-conflict free; the staging writes
+// (4..8 consecutive 16-byte pieces per pixel) are too.  For stride 2 the halo columns are stored
+// de-interleaved (even columns first) so that the 32 pixels of a fragment are again consecutive.
+#pragma once
+#include "yamd_common.h"
+
+#include <cstring>
+#include <cstdlib>
+#include <cmath>
+#include <mutex>
+#include <type_traits>
+
+namespace yamd {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvParams {
+    const __bf16 *x;
+    const char *w;
+    const float *bias;
+    const __bf16 *res;
+    void *y;
+    int x_cs, res_cs, y_cs;
+    int H, W, Hout, Wout, Cout;
+    int TH, tiles_x, tiles_y, n_tiles, nchunks;
+    int act;
+};
+
+// Activations on the fp32 accumulator with hardware exp/rcp (about 1 ulp each); the result is rounded to
+// bf16 (8 significant bits) or feeds raw logits only for YAMD_ACT_NONE, so this loses nothing.
+__device__ __forceinline__ float apply_act(float v, int act)
+{
+    switch (act) {
+    case YAMD_ACT_SILU:
+        return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+    case YAMD_ACT_LEAKY:
+        return fmaxf(v, 0.1f * v);
+    case YAMD_ACT_MISH: {
+        // tanh(log(1+e^v)) = n / (n + 2) with n = e^v (e^v + 2); v for large v (torch's softplus threshold 20)
+        const float e = __expf(fminf(v, 20.0f));
+        const float n = e * (e + 2.0f);
+        return v > 20.0f ? v : v * n * __builtin_amdgcn_rcpf(n + 2.0f);
+    }
+    case YAMD_ACT_RELU:
+        return fmaxf(v, 0.0f);
+    default:
+        return v;
+    }
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>); every array index
+// inside f is a constant, so staging arrays stay in registers
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+template <int ACT>
+__device__ __forceinline__ void act4(float (&v)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], ACT);
+}
+
+template <int KS, int S, int TW, int MREP, int NREP, int CK, bool OUT_F32, int ACTK>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
+{
+    constexpr int PAD = KS / 2;
+    constexpr int NPW = (TW - 1) * S + KS;   // halo width in input pixels
+    constexpr int NPWH = (NPW + 1) / 2;      // even-column count (stride-2 de-interleave)
+    constexpr int RS = CK * 2 + 16;          // LDS bytes per halo pixel
+    constexpr int G8 = CK / 8;               // 16-byte pieces per halo pixel
+    constexpr int KSTEPS = CK / 16;
+    constexpr int TAPS = KS * KS;
+    constexpr int WBYTES = TAPS * KSTEPS * NREP * 1024;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *ldsW = smem;
+    char *ldsA = smem + WBYTES;
+
+    int bid = blockIdx.x;
+    const int nt = bid % p.n_tiles;
+    bid /= p.n_tiles;
+    const int tx = bid % p.tiles_x;
+    bid /= p.tiles_x;
+    const int ty = bid % p.tiles_y;
+    const int b = bid / p.tiles_y;
+    const int oh0 = ty * p.TH, ow0 = tx * TW;
+    const int NPH = (p.TH - 1) * S + KS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c32 = lane & 31, g = lane >> 5;
+
+    // LDS byte offset of this lane's pixel (tap 0,0) for each 32-pixel fragment
+    int pixoff[MREP];
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) {
+        const int pp = wave * (32 * MREP) + m * 32 + c32;
+        int pr = pp / TW, pc = pp % TW;
+        if (pr >= p.TH) { pr = 0; pc = 0; }   // slot beyond the tile: read something valid, never stored
+        pixoff[m] = ((pr * S) * NPW + pc) * RS + g * 16;
+    }
+
+    // accumulators start at the bias: register 4i+j of fragment n is cout n*32 + 8i + 4g + j
+    f32x16 acc[MREP][NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 bv = *(const f32x4 *)(p.bias + nt * (NREP * 32) + n * 32 + 8 * i + 4 * g);
+#pragma unroll
+            for (int m = 0; m < MREP; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[m][n][4 * i + j] = bv[j];
+        }
+
+    // Staging registers: the next chunk's global loads are issued before the current chunk is computed
+    // and written to LDS afterwards, so HBM/L2 latency hides under the MFMA work.
+    constexpr int THMAX = (128 * MREP) / TW;
+    constexpr int NPHMAX = (THMAX - 1) * S + KS;
+    constexpr int AP = (NPHMAX * NPW * G8 + 255) / 256;   // activation pieces per thread
+    constexpr int WP = (WBYTES / 16 + 255) / 256;         // weight pieces per thread
+    u32x4 ra[AP], rw[WP];
+    const int total = NPH * NPW * G8;
+
+    // No divergent control flow in the staging: piece indices beyond the end are clamped (the duplicate
+    // loads/stores are benign) and out-of-image pixels load a clamped address and are zeroed by a select.
+    // The per-piece global offset (inside this image), LDS offset and in-image flag do not depend on the
+    // channel chunk, so they are computed once.
+    int goff[AP], loff[AP];
+    unsigned inb_mask = 0u;
+    static_for<AP>([&](auto uc) __attribute__((always_inline)) {
+        constexpr int u = decltype(uc)::value;
+        const int q = min(tid + u * 256, total - 1);
+        const int pix = q / G8, gc = q % G8;
+        const int hr = pix / NPW, hc = pix % NPW;
+        const int ih = oh0 * S - PAD + hr, iw = ow0 * S - PAD + hc;
+        const bool inb = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
+        goff[u] = (ihc * p.W + iwc) * p.x_cs + gc * 8;
+        const int lc = (S == 2) ? ((hc & 1) * NPWH + (hc >> 1)) : hc;
+        loff[u] = (hr * NPW + lc) * RS + gc * 16;
+        inb_mask |= inb ? (1u << u) : 0u;
+    });
+    const __bf16 *ximg = p.x + (size_t)b * p.H * p.W * p.x_cs;
+    const char *wtile = p.w + (size_t)nt * p.nchunks * WBYTES;
+    auto issue_loads = [&](int ch) __attribute__((always_inline)) {
+        const char *wsrc = wtile + (size_t)ch * WBYTES;
+        static_for<WP>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            const int q = min(tid + u * 256, WBYTES / 16 - 1);
+            rw[u] = *(const u32x4 *)(wsrc + q * 16);
+        });
+        const __bf16 *xc = ximg + ch * CK;
+        static_for<AP>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            const u32x4 v = *(const u32x4 *)(xc + goff[u]);
+            ra[u] = ((inb_mask >> u) & 1u) ? v : u32x4{0u, 0u, 0u, 0u};
+        });
+    };
+    auto write_lds = [&]() __attribute__((always_inline)) {
+        static_for<WP>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            const int q = min(tid + u * 256, WBYTES / 16 - 1);
+            *(u32x4 *)(ldsW + q * 16) = rw[u];
+        });
+        static_for<AP>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            *(u32x4 *)(ldsA + loff[u]) = ra[u];
+        });
+    };
+
+    issue_loads(0);
+    write_lds();
+    __syncthreads();
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        const bool more = ch + 1 < p.nchunks;
+        if (more) issue_loads(ch + 1);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int kh = tap / KS, kw = tap % KS;
+            const int tapoff = (S == 1) ? (kh * NPW + kw) * RS : (kh * NPW + (kw & 1) * NPWH + (kw >> 1)) * RS;
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) {
+                bf16x8 a[MREP], wv[NREP];
+#pragma unroll
+                for (int m = 0; m < MREP; ++m) a[m] = *(const bf16x8 *)(ldsA + pixoff[m] + tapoff + ks * 32);
+#pragma unroll
+                for (int n = 0; n < NREP; ++n)
+                    wv[n] = *(const bf16x8 *)(ldsW + ((tap * KSTEPS + ks) * NREP + n) * 1024 + lane * 16);
+#pragma unroll
+                for (int m = 0; m < MREP; ++m)
+#pragma unroll
+                    for (int n = 0; n < NREP; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[n], a[m], acc[m][n], 0, 0, 0);
+            }
+        }
+        __syncthreads();   // every wave is done reading this chunk
+        if (more) {
+            write_lds();
+            __syncthreads();
+        }
+    }
+
+    // epilogue: lane holds, for pixel c32 of each fragment, couts 8*i + 4*g + j (i,j = 0..3)
+    if constexpr (OUT_F32) {
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) {
+            const int pp = wave * (32 * MREP) + m * 32 + c32;
+            const int pr = pp / TW, pc = pp % TW;
+            const int oh = oh0 + pr, ow = ow0 + pc;
+            const bool valid = pr < p.TH && oh < p.Hout && ow < p.Wout;
+            const size_t pix = (size_t)(b * p.Hout + oh) * p.Wout + ow;
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = nt * (NREP * 32) + n * 32 + 8 * i + 4 * g;
+                    if (!valid || co >= p.Cout) continue;
+                    float *y = (float *)p.y + pix * p.y_cs + co;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (co + j < p.Cout) y[j] = apply_act(acc[m][n][4 * i + j], p.act);
+                }
+            }
+        }
+    } else {
+        // bf16 output goes through a per-wave LDS tile [32 pixels][BN couts] so that the global stores are
+        // 16 bytes per lane and whole pixel rows (BN*2 contiguous bytes) per group of lanes.
+        constexpr int RSO = NREP * 64 + 16;        // bytes per pixel row of the staging tile
+        constexpr int PPR = NREP * 4;              // 16-byte pieces per pixel
+        constexpr int PIXPI = 64 / PPR;            // pixels per wave store instruction
+        char *wreg = smem + wave * (32 * RSO);     // the chunk loop ended with a barrier: LDS is free
+        auto epilogue = [&](auto mc, auto ac) __attribute__((always_inline)) {
+            constexpr int m = decltype(mc)::value;
+            constexpr int ACT = decltype(ac)::value;
+            const int pp = wave * (32 * MREP) + m * 32 + c32;
+            const int pr = pp / TW, pc = pp % TW;
+            const bool valid = pr < p.TH && oh0 + pr < p.Hout && ow0 + pc < p.Wout;
+            const size_t pix = (size_t)(b * p.Hout + oh0 + pr) * p.Wout + ow0 + pc;
+#pragma unroll
+            for (int n = 0; n < NREP; ++n) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cl = n * 32 + 8 * i + 4 * g;
+                    const int co = nt * (NREP * 32) + cl;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[m][n][4 * i + j];
+                    act4<ACT>(v);
+                    if (p.res && valid && co < p.Cout) {
+                        const bf16x4 r = *(const bf16x4 *)(p.res + pix * p.res_cs + co);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+                    *(bf16x4 *)(wreg + c32 * RSO + cl * 2) = o;
+                }
+            }
+            // the tile is private to this wave: order the LDS writes before the cross-lane reads
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 32 / PIXPI; ++it) {
+                const int r = it * PIXPI + lane / PPR, piece = lane % PPR;
+                const uint4 v = *(const uint4 *)(wreg + r * RSO + piece * 16);
+                const int pq = wave * (32 * MREP) + m * 32 + r;
+                const int qr = pq / TW, qc = pq % TW;
+                const int co = nt * (NREP * 32) + piece * 8;
+                if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout && co < p.Cout)
+                    *(uint4 *)((__bf16 *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + co) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        };
+        // ACTK >= 0: the activation is a compile-time constant of this kernel (small code); ACTK < 0: one
+        // uniform branch on the activation kind for the whole epilogue
+        auto run = [&](auto ac) __attribute__((always_inline)) {
+            epilogue(std::integral_constant<int, 0>{}, ac);
+            if constexpr (MREP > 1) epilogue(std::integral_constant<int, 1>{}, ac);
+        };
+        if constexpr (ACTK >= 0) {
+            run(std::integral_constant<int, ACTK>{});
+        } else {
+            switch (p.act) {
+            case YAMD_ACT_LEAKY: run(std::integral_constant<int, YAMD_ACT_LEAKY>{}); break;
+            case YAMD_ACT_MISH: run(std::integral_constant<int, YAMD_ACT_MISH>{}); break;
+            case YAMD_ACT_RELU: run(std::integral_constant<int, YAMD_ACT_RELU>{}); break;
+            case YAMD_ACT_SILU: run(std::integral_constant<int, YAMD_ACT_SILU>{}); break;
+            default: run(std::integral_constant<int, YAMD_ACT_NONE>{}); break;
+            }
+        }
+    }
+}
+
+template <int KS, int S, int TW, int MREP, int NREP, int CK, bool OUT_F32, int ACTK>
+int launch_conv(const ConvParams &p, int batch, hipStream_t stream)
+{
+    constexpr int NPW = (TW - 1) * S + KS;
+    constexpr int RS = CK * 2 + 16;
+    constexpr int WBYTES = KS * KS * (CK / 16) * NREP * 1024;
+    const int NPH = (p.TH - 1) * S + KS;
+    size_t lds = (size_t)WBYTES + (size_t)NPH * NPW * RS;
+    if (!OUT_F32 && lds < (size_t)4 * 32 * (NREP * 64 + 16)) lds = (size_t)4 * 32 * (NREP * 64 + 16);
+    YAMD_REQUIRE(lds <= 160 * 1024, "conv tile needs %zu bytes of LDS", lds);
+    auto kern = conv_igemm_kernel<KS, S, TW, MREP, NREP, CK, OUT_F32, ACTK>;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [&] {
+        attr_err = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    YAMD_HIP(attr_err);
+    const long long grid = (long long)batch * p.tiles_y * p.tiles_x * p.n_tiles;
+    YAMD_REQUIRE(grid > 0 && grid < (1ll << 31), "conv grid out of range");
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
+    YAMD_LAUNCH_CHECK();
+    return YAMD_OK;
+}
+
+// one tiling, both tile widths, SiLU-specialised or run-time activation
+template <int KS, int S, int MREP, int NREP, int CK, bool OUT_F32>
+int launch_conv_variant(const ConvParams &p, int batch, int tw, hipStream_t st)
+{
+    if constexpr (OUT_F32) {
+        return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, true, -1>(p, batch, st)
+                        : launch_conv<KS, S, 20, MREP, NREP, CK, true, -1>(p, batch, st);
+    } else {
+        if (p.act == YAMD_ACT_SILU)
+            return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, false, YAMD_ACT_SILU>(p, batch, st)
+                            : launch_conv<KS, S, 20, MREP, NREP, CK, false, YAMD_ACT_SILU>(p, batch, st);
+        return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, false, -1>(p, batch, st)
+                        : launch_conv<KS, S, 20, MREP, NREP, CK, false, -1>(p, batch, st);
+    }
+}
+
+// tile width: prefer an exact divisor of the output width
+inline int pick_tw(int wout) { return (wout % 16 == 0) ? 16 : ((wout % 20 == 0 || wout % 10 == 0) ? 20 : 16); }
+
+}  // namespace yamd
