@@ -8,7 +8,9 @@ confidence filter + per-class NMS -> detections on the host), batch 256 per MI35
 
 One step = one pass of the whole path over one batch that is already resident in HBM: 62 fused
 conv kernels (bf16 MFMA), head decode, NMS, then the compacted detections are copied to the host
-(counts + the kept rows), which is what the reference's ``predict`` returns.
+(counts + the kept rows), which is what the reference's ``predict`` returns.  The device->host copy of
+step i runs on a second stream under step i+1's kernels; all K steps' detections are on the host
+before the clock stops.
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -91,33 +93,77 @@ def build_model(weights: str):
 
 
 class HostSink:
-    """Per-step device->host hand-over of the detections: rows packed back to back on the device, then
-    one copy of the (B+1) offsets (synchronises) and one contiguous copy of the kept rows into pinned memory."""
+    """Device->host hand-over of the detections, pipelined one step deep.
+
+    Per step the kept rows are packed back to back on the device (compute stream); a second stream then
+    copies the (B+1) offsets and, once the host knows the total, the kept rows into pinned memory.  The host
+    only waits for step i's offsets after it has enqueued step i+1's kernels, so the copies and the host-side
+    launch work overlap the next step's compute.  Two device/host buffer sets alternate; ``drain`` completes
+    the last step.  Every step's rows are on the host when ``drain`` returns."""
 
     def __init__(self, batch, a, width, device):
         from yolo_amd import lib as L
         self.L = L
         self.width = width
-        self.compact = torch.empty((batch * a, width), dtype=torch.float32, device=device)
-        self.offsets = torch.empty((batch + 1,), dtype=torch.int64, device=device)
-        self.h_offsets = torch.empty((batch + 1,), dtype=torch.int64).pin_memory()
-        self.h_rows = torch.empty((batch * a, width), dtype=torch.float32).pin_memory()
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.slots = []
+        for _ in range(2):
+            self.slots.append(dict(
+                compact=torch.empty((batch * a, width), dtype=torch.float32, device=device),
+                offsets=torch.empty((batch + 1,), dtype=torch.int64, device=device),
+                h_offsets=torch.empty((batch + 1,), dtype=torch.int64).pin_memory(),
+                h_rows=torch.empty((batch * a, width), dtype=torch.float32).pin_memory(),
+                packed=torch.cuda.Event(), offsets_done=torch.cuda.Event(), rows_done=None, keep=None))
+        self.n = 0
+        self.pending = None
+        self.last_total = 0
+        self.h_offsets = self.slots[0]["h_offsets"]
 
-    def fetch(self, rows, counts):
+    def submit(self, rows, counts):
+        """Enqueue packing + the offsets copy of this step, then complete the previous step's row copy."""
         L = self.L
+        slot = self.slots[self.n % 2]
+        self.n += 1
+        cur = torch.cuda.current_stream()
+        if slot["rows_done"] is not None:
+            cur.wait_event(slot["rows_done"])          # the copy that last read this slot's device buffer
         B, max_out, W = rows.shape
-        L.check(L.LIB.yamd_compact_rows(rows.data_ptr(), counts.data_ptr(), B, max_out, W, self.compact.data_ptr(),
-                                        self.offsets.data_ptr(), L.current_stream()), "compact_rows")
-        self.h_offsets.copy_(self.offsets, non_blocking=False)     # synchronises: the total decides how much to copy
-        total = int(self.h_offsets[-1])
-        if total:
-            self.h_rows[:total].copy_(self.compact[:total], non_blocking=False)
-        return total
+        L.check(L.LIB.yamd_compact_rows(rows.data_ptr(), counts.data_ptr(), B, max_out, W, slot["compact"].data_ptr(),
+                                        slot["offsets"].data_ptr(), L.current_stream()), "compact_rows")
+        slot["packed"].record(cur)
+        slot["keep"] = (rows, counts)                  # keep the producers' memory alive until packed
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(slot["packed"])
+            slot["h_offsets"].copy_(slot["offsets"], non_blocking=True)
+            slot["offsets_done"].record(self.copy_stream)
+        prev, self.pending = self.pending, slot
+        if prev is not None:
+            self._finish(prev)
+
+    def _finish(self, slot):
+        slot["offsets_done"].synchronize()
+        total = int(slot["h_offsets"][-1])
+        with torch.cuda.stream(self.copy_stream):
+            if total:
+                slot["h_rows"][:total].copy_(slot["compact"][:total], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+            slot["rows_done"] = ev
+        slot["keep"] = None
+        self.last_total = total
+        self.h_offsets = slot["h_offsets"]
+
+    def drain(self):
+        if self.pending is not None:
+            self._finish(self.pending)
+            self.pending = None
+        self.copy_stream.synchronize()
+        return self.last_total
 
 
 def step(model, images, sink):
     rows, counts = model.predict_device(images)
-    return sink.fetch(rows, counts)
+    sink.submit(rows, counts)
 
 
 def stage_profile(model, p, images, reps=3):
@@ -208,10 +254,12 @@ def main():
 
     for _ in range(args.warmup):
         step(model, images, sink)
+    sink.drain()
     barrier(world, False)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        total_kept = step(model, images, sink)
+        step(model, images, sink)
+    sink.drain()                      # the last step's detections are on the host before the clock stops
     barrier(world, False)
     elapsed = max_over_ranks(time.perf_counter() - t0, world, False)
 
