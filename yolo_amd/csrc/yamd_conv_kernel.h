@@ -354,7 +354,11 @@ int launch_conv_variant(const ConvParams &p, int batch, int tw, hipStream_t st)
     }
 }
 
-// tile width: prefer an exact divisor of the output width
-inline int pick_tw(int wout) { return (wout % 16 == 0) ? 16 : ((wout % 20 == 0 || wout % 10 == 0) ? 20 : 16); }
+// tile width: the one that covers the output width with the least padding (16 on a tie)
+inline int pick_tw(int wout)
+{
+    const int c16 = ceil_div(wout, 16) * 16, c20 = ceil_div(wout, 20) * 20;
+    return c20 < c16 ? 20 : 16;
+}
 
 }  // namespace yamd

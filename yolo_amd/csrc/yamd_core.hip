@@ -115,6 +115,25 @@ __device__ __forceinline__ bf16x8 max8(bf16x8 a, bf16x8 b)
     return r;
 }
 
+__global__ void maxpool2_kernel(const __bf16 *__restrict__ x, int x_cs, __bf16 *__restrict__ y, int y_cs, int B, int H,
+                                int W, int C8)
+{
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)B * Ho * Wo * C8;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        const long long pix = i / C8;
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const long long b = pix / ((long long)Wo * Ho);
+        const __bf16 *s = x + ((b * H + 2 * oy) * W + 2 * ox) * x_cs + c8 * 8;
+        const bf16x8 a = *(const bf16x8 *)s, c = *(const bf16x8 *)(s + x_cs);
+        const bf16x8 d = *(const bf16x8 *)(s + (long long)W * x_cs), e = *(const bf16x8 *)(s + (long long)(W + 1) * x_cs);
+        *(bf16x8 *)(y + pix * y_cs + c8 * 8) = max8(max8(a, c), max8(d, e));
+    }
+}
+
 // One workgroup per (image, 8-channel piece): the whole h*w plane of 16-byte pixels sits in LDS;
 // a 5x5 max is a 5-tap row pass followed by a 5-tap column pass, applied three times.
 __global__ void maxpool5_cascade_kernel(const __bf16 *__restrict__ x, int x_cs, __bf16 *__restrict__ y1,
@@ -209,6 +228,21 @@ extern "C" int yamd_copy_channels(const void *x, int x_cstride, void *y, int y_c
                  "copy needs 16-byte aligned pixels");
     hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(pixels * (c / 8), 256)), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16 *)x, x_cstride, (__bf16 *)y, y_cstride, pixels, c / 8);
+    YAMD_LAUNCH_CHECK();
+    return YAMD_OK;
+}
+
+extern "C" int yamd_maxpool2(const void *x, int x_cstride, void *y, int y_cstride, int batch, int h, int w, int c,
+                             void *stream)
+{
+    YAMD_REQUIRE(x && y, "null argument");
+    YAMD_REQUIRE(batch > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0 && c > 0 && c % 8 == 0,
+                 "maxpool2: bad shape %dx%dx%d", h, w, c);
+    YAMD_REQUIRE(x_cstride % 8 == 0 && y_cstride % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0,
+                 "maxpool2 needs 16-byte aligned pixels");
+    const long long total = (long long)batch * (h / 2) * (w / 2) * (c / 8);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16 *)x,
+                       x_cstride, (__bf16 *)y, y_cstride, batch, h, w, c / 8);
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
 }

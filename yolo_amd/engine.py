@@ -65,6 +65,7 @@ class Program:
         self.ops: List[tuple] = []
         self.convs: List[ConvLayer] = []
         self.outputs: Dict[str, View] = {}
+        self.alias: Dict[str, Tuple[str, int]] = {}     # buffer -> (wider buffer it lives in, first channel)
         self._alloc: Dict[Tuple[int, str], Dict[str, torch.Tensor]] = {}
         self._n = 0
 
@@ -104,7 +105,9 @@ class Program:
         self.ops.append(("conv", layer, x, out, residual))
         return out
 
-    def upsample2x(self, x: View, out: View) -> View:
+    def upsample2x(self, x: View, out: Optional[View] = None) -> View:
+        if out is None:
+            out = self.buffer(2 * x.h, 2 * x.w, x.c)
         assert (out.h, out.w, out.c) == (2 * x.h, 2 * x.w, x.c)
         self.ops.append(("up2", x, out))
         return out
@@ -119,6 +122,48 @@ class Program:
         self.ops.append(("copy", x, out))
         return out
 
+    def maxpool2(self, x: View, out: Optional[View] = None) -> View:
+        """MaxPool2d(kernel 2, stride 2)."""
+        assert x.h % 2 == 0 and x.w % 2 == 0
+        if out is None:
+            out = self.buffer(x.h // 2, x.w // 2, x.c)
+        assert (out.h, out.w, out.c) == (x.h // 2, x.w // 2, x.c)
+        self.ops.append(("mp2", x, out))
+        return out
+
+    def cat(self, views: List[View], name: Optional[str] = None) -> View:
+        """torch.cat(views, dim=1) without moving data where possible: a source that is a whole buffer of its
+        own is re-homed into the concat buffer (its producers then write their channel slice in place, also
+        the ones recorded earlier); a source that already lives elsewhere (a slice, or a tensor that is part
+        of another concat) is copied."""
+        assert views and all((v.h, v.w) == (views[0].h, views[0].w) for v in views)
+        merged: List[View] = []
+        for v in views:                                   # adjacent slices of one buffer count as one source
+            if merged and merged[-1].buf == v.buf and merged[-1].coff + merged[-1].c == v.coff:
+                merged[-1] = View(v.buf, merged[-1].coff, merged[-1].c + v.c, v.h, v.w)
+            else:
+                merged.append(v)
+        total = sum(v.c for v in merged)
+        out = self.buffer(views[0].h, views[0].w, total, name=name)
+        off = 0
+        for v in merged:
+            h, w, c, dt = self.buffers[v.buf]
+            whole = v.coff == 0 and v.c == c and v.buf not in self.alias and dt == torch.bfloat16
+            if whole and v.buf not in {o.buf for o in self.outputs.values()}:
+                self.alias[v.buf] = (out.buf, off)
+            else:
+                self.copy(v, out.slice(off, v.c))
+            off += v.c
+        return out
+
+    def resolve(self, v: View) -> Tuple[str, int]:
+        """(root buffer, first channel inside it) of a view after following the re-homing chain."""
+        buf, coff = v.buf, v.coff
+        while buf in self.alias:
+            buf, o = self.alias[buf]
+            coff += o
+        return buf, coff
+
     # ---- accounting ------------------------------------------------------------------------------
     def conv_macs_per_image(self) -> int:
         total = 0
@@ -128,7 +173,8 @@ class Program:
         return total
 
     def activation_bytes_per_image(self) -> int:
-        return sum(h * w * c * (2 if dt == torch.bfloat16 else 4) for h, w, c, dt in self.buffers.values())
+        return sum(h * w * c * (2 if dt == torch.bfloat16 else 4) for n, (h, w, c, dt) in self.buffers.items()
+                   if n not in self.alias)
 
     def op_cost(self, op, batch: int) -> Tuple[float, float]:
         """(algorithmic flops, algorithmic bytes) of one recorded op for a batch: every input and output
@@ -153,6 +199,8 @@ class Program:
             return 0.0, float(batch * op[1].h * op[1].w * op[1].c * 2 * 4)
         if kind == "copy":
             return 0.0, float(batch * op[1].h * op[1].w * op[1].c * 2 * 2)
+        if kind == "mp2":
+            return 0.0, float(batch * op[1].h * op[1].w * op[1].c * 2 * 1.25)
         return 0.0, 0.0
 
     # ---- execution -------------------------------------------------------------------------------
@@ -161,15 +209,15 @@ class Program:
         if key not in self._alloc:
             self._alloc.clear()   # one live batch size at a time: the arena is large
             self._alloc[key] = {n: torch.empty((batch, h, w, c), dtype=dt, device=device)
-                                for n, (h, w, c, dt) in self.buffers.items()}
+                                for n, (h, w, c, dt) in self.buffers.items() if n not in self.alias}
             for layer in self.convs:
                 layer.to(device)
         return self._alloc[key]
 
-    @staticmethod
-    def _ptr(bufs: Dict[str, torch.Tensor], v: View) -> Tuple[int, int]:
-        t = bufs[v.buf]
-        return t.data_ptr() + v.coff * t.element_size(), t.shape[-1]
+    def _ptr(self, bufs: Dict[str, torch.Tensor], v: View) -> Tuple[int, int]:
+        buf, coff = self.resolve(v)
+        t = bufs[buf]
+        return t.data_ptr() + coff * t.element_size(), t.shape[-1]
 
     def run(self, images: torch.Tensor, timings: Optional[list] = None) -> Dict[str, torch.Tensor]:
         """images: (B,3,H,W) float32 NCHW on the GPU.  Returns {output name: tensor view}; raw head
@@ -219,6 +267,11 @@ class Program:
                 xp, xcs = P(bufs, x)
                 yp, ycs = P(bufs, out)
                 _lib.check(LIB.yamd_copy_channels(xp, xcs, yp, ycs, B * x.h * x.w, x.c, st), "copy")
+            elif kind == "mp2":
+                _, x, out = op
+                xp, xcs = P(bufs, x)
+                yp, ycs = P(bufs, out)
+                _lib.check(LIB.yamd_maxpool2(xp, xcs, yp, ycs, B, x.h, x.w, x.c, st), "maxpool2")
             else:
                 raise AssertionError(kind)
             if timings is not None:
@@ -227,6 +280,7 @@ class Program:
                 timings.append((kind, op[1].name if kind == "conv" else kind, ev0, ev1) + self.op_cost(op, B))
         res = {}
         for name, v in self.outputs.items():
-            t = bufs[v.buf]
-            res[name] = t if (v.coff == 0 and v.c == t.shape[-1]) else t[..., v.coff:v.coff + v.c]
+            buf, coff = self.resolve(v)
+            t = bufs[buf]
+            res[name] = t if (coff == 0 and v.c == t.shape[-1]) else t[..., coff:coff + v.c]
         return res
