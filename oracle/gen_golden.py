@@ -32,6 +32,7 @@ from luoyang.yolov7_pose.YoloV7PoseHead import YoloV7PoseHead  # noqa: E402
 from luoyang.yolov8.YoloV8 import YoloV8  # noqa: E402
 from luoyang.yolov8.YoloV8Head import YoloV8Head  # noqa: E402
 
+from yolo_amd import models as _models  # noqa: E402
 from yolo_amd.init import seeded_images, seeded_state_dict  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -267,6 +268,7 @@ def _ref_models():
     """name -> (reference class, param factory, raw head order of body_net, row width, small size)"""
     return {
         "v8s": (YoloV8, lambda: Yolo8Param(m_type="s"), "asc", 7, 64),
+        "v3": (YoloV3, lambda: Yolo3Param(), "desc", 7, 64),
     }
 
 
@@ -284,7 +286,7 @@ def gen_model(name):
             if hasattr(p, attr):
                 setattr(p, attr, None)
         model = cls(p).eval()
-        sd = seeded_state_dict(model, seed=seed, mode="spread")
+        sd = seeded_state_dict(model, seed=seed, mode="spread", **_models.init_options(name))
         model.load_state_dict(sd, strict=True)
         imgs = torch.from_numpy(seeded_images(batch, size, seed=seed))
         with torch.no_grad():

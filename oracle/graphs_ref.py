@@ -93,6 +93,43 @@ def v8_body(sd: SD, images: torch.Tensor) -> List[torch.Tensor]:
 
 
 # ------------------------------------------------------------------------------------------------
+# YOLOv3: luoyang/yolov3/DarkNet53.py BasicBlock :10-47 (x + conv3x3(conv1x1(x)), BN eps 1e-5, LeakyReLU 0.1),
+# _make_layer :50-61, DarkNet53.forward :90-107; luoyang/yolov3/YoloV3BackBone.py forward :78-105
+# ------------------------------------------------------------------------------------------------
+def _v3_cbl(sd, p, x, s=1):
+    return conv_bn_act(sd, p + ".conv", p + ".bn", x, s, leaky, 1e-5)
+
+
+def _v3_last(sd, p, x):
+    for k in range(5):
+        x = _v3_cbl(sd, f"{p}.{k}", x)
+    out = F.conv2d(_v3_cbl(sd, f"{p}.5", x), sd[f"{p}.6.weight"], sd[f"{p}.6.bias"])
+    return x, out
+
+
+def v3_body(sd: SD, images: torch.Tensor) -> List[torch.Tensor]:
+    """images (B,3,S,S) -> raw heads [stride 8, 16, 32], each (B, 3*(5+nc), h, w)."""
+    d = "body_net.darknet53."
+    x = conv_bn_act(sd, d + "conv1.0", d + "conv1.1", images, 1, leaky, 1e-5)
+    feats = []
+    for i in range(1, 6):
+        lp = f"{d}layer_{i}"
+        x = _v3_cbl(sd, lp, x, 2)
+        for j in range(_count(sd, lp + ".residual_{}.conv.0.weight")):
+            rp = f"{lp}.residual_{j}.conv."
+            t = conv_bn_act(sd, rp + "0", rp + "1", x, 1, leaky, 1e-5)
+            x = x + conv_bn_act(sd, rp + "3", rp + "4", t, 1, leaky, 1e-5)
+        feats.append(x)
+    x2, x1, x0 = feats[2], feats[3], feats[4]
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+    n = "body_net."
+    b0, out0 = _v3_last(sd, n + "last_layer0", x0)
+    b1, out1 = _v3_last(sd, n + "last_layer1", torch.cat((up(_v3_cbl(sd, n + "last_layer1_conv", b0)), x1), 1))
+    _, out2 = _v3_last(sd, n + "last_layer2", torch.cat((up(_v3_cbl(sd, n + "last_layer2_conv", b1)), x2), 1))
+    return [out2, out1, out0]
+
+
+# ------------------------------------------------------------------------------------------------
 # per-model glue: body graph, decode of its raw heads, NMS flavour of its predict()
 # ------------------------------------------------------------------------------------------------
 def model_ref(name: str):
@@ -108,4 +145,8 @@ def model_ref(name: str):
                     decode=lambda raws, p, predict: decode_ref.decode_dfl(raws, p.strides, 16, p.class_num,
                                                                           "xyxy" if predict else "cxcywh"),
                     nms=dict(in_fmt="xyxy"))
+    if name == "v3":
+        return dict(body=v3_body,
+                    decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "v3"),
+                    nms=dict(in_fmt="cxcywh"))
     raise KeyError(name)

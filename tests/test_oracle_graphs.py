@@ -11,14 +11,14 @@ from oracle import graphs_ref, postprocess
 from yolo_amd import models
 from yolo_amd.init import seeded_images, seeded_state_dict
 
-NAMES = ["v8s"]
+NAMES = ["v8s", "v3"]
 
 
 def _setup(name, which):
     g = load_golden(f"{name}_{which}.npz")
     size, batch, seed = int(g["size"]), int(g["batch"]), int(g["seed"])
     p, model = models.create(name, size)
-    sd = seeded_state_dict(model, seed=seed, mode="spread")
+    sd = seeded_state_dict(model, seed=seed, mode="spread", **models.init_options(name))
     imgs = torch.from_numpy(seeded_images(batch, size, seed=seed))
     return g, p, model, sd, imgs
 

@@ -95,3 +95,64 @@ class TaskModel(nn.Module):
 
     def to_onnx(self, onnx_path: str):
         raise NotImplementedError("ONNX export is outside the accelerated path; use the reference for export")
+
+
+class AnchorTaskModel(TaskModel):
+    """Anchor-based families (v3, v4, v5, v7 pose/face): three raw heads -> per-level decode -> merge -> NMS.
+    Subclasses provide ``_compile`` (outputs "P3","P4","P5") and set the class attributes below.  The methods
+    follow e.g. luoyang/yolov3/YoloV3.py: ``_feed_forward`` :66-83, ``predict`` :118-148, ``_forward`` :191-213 and
+    luoyang/yolov7_pose/YoloV7Pose.py:57-83, :132-168 (keypoint columns scaled too, clamped in ``predict`` only)."""
+
+    DECODE_KIND = _lib.DECODE_V5
+    POINT_NUM = 0            # keypoints / landmarks per box
+    POINT_CONF = False       # True: one confidence column per keypoint (pose)
+
+    def raw_heads(self, images: torch.Tensor) -> List[torch.Tensor]:
+        """Raw head logits [P3, P4, P5], float32 NHWC (B,h,w,3*C)."""
+        out = self.program().run(images)
+        return [out["P3"], out["P4"], out["P5"]]
+
+    def _level_anchors(self, level: int):
+        na = self.param.anchor_num
+        return self.param.anchors[level * na:(level + 1) * na]
+
+    def _merge(self, raws, clamp_points: bool) -> torch.Tensor:
+        return torch_utils.decode_anchor_levels(raws, self.param.anchors, self.param.strides, self.param.img_size,
+                                                self.DECODE_KIND, self.POINT_NUM, clamp_points)
+
+    def _forward(self, images: torch.Tensor) -> List[torch.Tensor]:
+        """[(B, A, C)] merged over levels, cxcywh in input pixels."""
+        return [self._merge(self.raw_heads(images), False)]
+
+    def _feed_forward(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:
+        raws = self.raw_heads(tensor_dict["batch_images"])
+        for i, name in enumerate(("head3_predicts", "head4_predicts", "head5_predicts")):
+            tensor_dict[name] = torch_utils.decode_anchor_head(raws[i], self._level_anchors(i), self.param.strides[i],
+                                                               self.DECODE_KIND, self.POINT_NUM)
+        tensor_dict["_raw_heads"] = raws
+        return tensor_dict
+
+    def forward(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:
+        """Inference keys only (``head3/4/5_predicts``); target assignment belongs to training."""
+        tensor_dict = self._feed_forward(tensor_dict)
+        tensor_dict.pop("_raw_heads")
+        return tensor_dict
+
+    def _n_extra(self) -> int:
+        return (3 if self.POINT_CONF else 2) * self.POINT_NUM
+
+    def predict_device(self, images: torch.Tensor):
+        """Whole path on the device: returns (rows (B,A,W), counts (B,)) without synchronising."""
+        pred = self._merge(self.raw_heads(images), self.POINT_NUM > 0 and self.POINT_CONF)
+        rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "cxcywh", self.param.conf_threshold,
+                                                  self.param.nms_threshold, self._n_extra())
+        return rows, counts
+
+    def predict(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:
+        """Adds ``predicts``: per image ``None`` or ndarray (K, W) in the reference's row layout."""
+        tensor_dict = self._feed_forward(tensor_dict)
+        pred = self._merge(tensor_dict.pop("_raw_heads"), self.POINT_NUM > 0 and self.POINT_CONF)
+        rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "cxcywh", self.param.conf_threshold,
+                                                  self.param.nms_threshold, self._n_extra())
+        tensor_dict["predicts"] = torch_utils.rows_to_host(rows, counts)     # one packed D2H for the batch
+        return tensor_dict

@@ -16,7 +16,10 @@ import numpy as np
 import torch
 
 
-def seeded_state_dict(model: torch.nn.Module, seed: int = 0, mode: str = "spread") -> "OrderedDict[str, torch.Tensor]":
+def seeded_state_dict(model: torch.nn.Module, seed: int = 0, mode: str = "spread", scale: Dict[str, float] = None
+                      ) -> "OrderedDict[str, torch.Tensor]":
+    """``scale`` maps a key suffix to a factor applied to the generated tensor (e.g. damping the last conv
+    of every residual branch so that a deep residual stack keeps its activation range)."""
     rng = np.random.RandomState(seed)
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     for name, ref in model.state_dict().items():
@@ -52,6 +55,9 @@ def seeded_state_dict(model: torch.nn.Module, seed: int = 0, mode: str = "spread
                 v = rng.uniform(-bound, bound, shape)
         else:
             v = ref.detach().cpu().double().numpy()                # constants (e.g. DFL projection)
+        for suffix, factor in (scale or {}).items():
+            if name.endswith(suffix):
+                v = np.asarray(v) * factor
         out[name] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape).copy())
     return out
 

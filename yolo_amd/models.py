@@ -1,22 +1,32 @@
-"""Name -> (model class, parameter factory) for the model families built on the HIP path; the names are
-the ones tests, goldens and the benchmark use."""
-from typing import Callable, Dict, Tuple
+"""Name -> model class, parameter factory and seeded-initialiser options for the model families built on the
+HIP path; the names are the ones tests, goldens and the benchmark use."""
+from typing import Any, Dict
 
 from . import param as _param
 
 
-def registry() -> Dict[str, Tuple[type, Callable[[], _param.Param]]]:
+def registry() -> Dict[str, Dict[str, Any]]:
+    from .yolov3 import YoloV3
     from .yolov5 import YoloV5
     from .yolov8 import YoloV8
     return {
-        "v5s": (YoloV5, lambda: _param.Yolo5Param(m_type="s").set_img_size(640)),
-        "v8s": (YoloV8, lambda: _param.Yolo8Param(m_type="s")),
+        "v5s": dict(cls=YoloV5, param=lambda: _param.Yolo5Param(m_type="s").set_img_size(640), init={}),
+        "v8s": dict(cls=YoloV8, param=lambda: _param.Yolo8Param(m_type="s"), init={}),
+        # 23 un-normalised residual adds: damp the branch output so random-init activations stay in range, and the
+        # head convs so that the logits (w,h go through exp) have a std of 1-2
+        "v3": dict(cls=YoloV3, param=lambda: _param.Yolo3Param().set_img_size(608),
+                   init=dict(scale={".conv.3.weight": 0.25, ".6.weight": 0.05})),
     }
 
 
+def init_options(name: str) -> Dict[str, Any]:
+    """Keyword arguments for ``init.seeded_state_dict`` that go with this model's goldens."""
+    return dict(registry()[name]["init"])
+
+
 def create(name: str, img_size: int = 0):
-    cls, mk = registry()[name]
-    p = mk()
+    e = registry()[name]
+    p = e["param"]()
     if img_size:
         p.set_img_size(img_size)
-    return p, cls(p)
+    return p, e["cls"](p)
