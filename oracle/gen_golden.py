@@ -20,10 +20,11 @@ from oracle import ref_harness  # noqa: E402
 
 ref_harness.install()
 
-from luoyang.param.Param import Yolo3Param, Yolo5Param, Yolo7FaceParam, Yolo7PoseParam, Yolo8Param  # noqa: E402
+from luoyang.param.Param import Yolo3Param, Yolo4Param, Yolo5Param, Yolo7FaceParam, Yolo7PoseParam, Yolo8Param  # noqa: E402
 from luoyang.utils import torch_utils as ref_tu  # noqa: E402
 from luoyang.yolov3.YoloHead import YoloHead  # noqa: E402
 from luoyang.yolov3.YoloV3 import YoloV3  # noqa: E402
+from luoyang.yolov4.YoloV4 import YoloV4  # noqa: E402
 from luoyang.yolov5.YoloV5 import YoloV5  # noqa: E402
 from luoyang.yolov5.YoloV5Head import YoloV5Head  # noqa: E402
 from luoyang.yolov7_face.YoloV7FaceHead import YoloV7FaceHead  # noqa: E402
@@ -269,6 +270,7 @@ def _ref_models():
     return {
         "v8s": (YoloV8, lambda: Yolo8Param(m_type="s"), "asc", 7, 64),
         "v3": (YoloV3, lambda: Yolo3Param(), "desc", 7, 64),
+        "v4": (YoloV4, lambda: Yolo4Param(), "desc", 7, 64),
     }
 
 
@@ -300,6 +302,14 @@ def gen_model(name):
                  conf_threshold=p.conf_threshold, nms_threshold=p.nms_threshold)
         if size == small:
             d.update(pred=_np(pred), **{f"raw{i}": _np(r) for i, r in enumerate(raws)})
+            try:                       # the reference's own fuse(): checkpoint layout + outputs after it
+                model.fuse()
+                fs = model.state_dict()
+                with torch.no_grad():
+                    d.update(fused_n_keys=len(fs), fused_pred=_np(model._forward(imgs)[0]),
+                             fused_bias_keys=np.array(sorted(k for k in fs if k.endswith(".bias"))[:6]))
+            except (NotImplementedError, TypeError) as e:
+                print(name, "reference fuse() unavailable:", repr(e))
         else:
             sel = np.arange(0, pred.shape[1], 37)
             d.update(pred_rows=sel, pred=_np(pred)[:, sel], raw_last=_np(raws[-1]))

@@ -130,6 +130,57 @@ def v3_body(sd: SD, images: torch.Tensor) -> List[torch.Tensor]:
 
 
 # ------------------------------------------------------------------------------------------------
+# YOLOv4: luoyang/yolov4/YoloV4BackBone.py BasicConv :18-43 (Mish), ResBlock :46-59, ResBlockBody :62-93,
+# CSPDarkNet.forward :119-127, conv2d :137-148 (LeakyReLU 0.1), SPP :151-162 ([13,9,5,x]), forward :233-262;
+# BN eps 1e-5; a backbone fused by YoloV4.fuse (:216-221) has conv.bias and no bn keys
+# ------------------------------------------------------------------------------------------------
+def _v4_basic(sd, p, x, s=1):
+    return conv_bn_act(sd, p + ".conv", p + ".bn", x, s, mish, 1e-5)
+
+
+def _v4_seq(sd, p, x, n):
+    for k in range(n):
+        x = _v3_cbl(sd, f"{p}.{k}", x)
+    return x
+
+
+def v4_body(sd: SD, images: torch.Tensor) -> List[torch.Tensor]:
+    """images (B,3,S,S) -> raw heads [stride 8, 16, 32], each (B, 3*(5+nc), h, w)."""
+    b = "body_net.backbone."
+    x = _v4_basic(sd, b + "conv1", images)
+    feats = []
+    for i in range(5):
+        sp = f"{b}stages.{i}."
+        x = _v4_basic(sd, sp + "downsample_conv", x, 2)
+        x0 = _v4_basic(sd, sp + "split_conv0", x)
+        x1 = _v4_basic(sd, sp + "split_conv1", x)
+        nres = _count(sd, sp + "blocks_conv.{}.block.0.conv.weight")
+        for j in range(nres):
+            rp = f"{sp}blocks_conv.{j}.block."
+            x1 = x1 + _v4_basic(sd, rp + "1", _v4_basic(sd, rp + "0", x1))
+        x1 = _v4_basic(sd, f"{sp}blocks_conv.{nres}", x1)
+        x = _v4_basic(sd, sp + "concat_conv", torch.cat((x1, x0), 1))
+        feats.append(x)
+    x2, x1, x0 = feats[2], feats[3], feats[4]
+    n = "body_net."
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+    p5 = _v4_seq(sd, n + "conv1", x0, 3)
+    p5 = torch.cat([F.max_pool2d(p5, k, 1, k // 2) for k in (13, 9, 5)] + [p5], 1)
+    p5 = _v4_seq(sd, n + "conv2", p5, 3)
+    p4 = torch.cat((_v3_cbl(sd, n + "conv_for_P4", x1), up(_v3_cbl(sd, n + "up_sample1.up_sample.0", p5))), 1)
+    p4 = _v4_seq(sd, n + "make_five_conv1", p4, 5)
+    p3 = torch.cat((_v3_cbl(sd, n + "conv_for_P3", x2), up(_v3_cbl(sd, n + "up_sample2.up_sample.0", p4))), 1)
+    p3 = _v4_seq(sd, n + "make_five_conv2", p3, 5)
+    p4 = _v4_seq(sd, n + "make_five_conv3", torch.cat((_v3_cbl(sd, n + "down_sample1", p3, 2), p4), 1), 5)
+    p5 = _v4_seq(sd, n + "make_five_conv4", torch.cat((_v3_cbl(sd, n + "down_sample2", p4, 2), p5), 1), 5)
+    outs = []
+    for head, t in (("yolo_head3", p3), ("yolo_head2", p4), ("yolo_head1", p5)):
+        h = _v3_cbl(sd, f"{n}{head}.0", t)
+        outs.append(F.conv2d(h, sd[f"{n}{head}.1.weight"], sd[f"{n}{head}.1.bias"]))
+    return outs
+
+
+# ------------------------------------------------------------------------------------------------
 # per-model glue: body graph, decode of its raw heads, NMS flavour of its predict()
 # ------------------------------------------------------------------------------------------------
 def model_ref(name: str):
@@ -145,8 +196,8 @@ def model_ref(name: str):
                     decode=lambda raws, p, predict: decode_ref.decode_dfl(raws, p.strides, 16, p.class_num,
                                                                           "xyxy" if predict else "cxcywh"),
                     nms=dict(in_fmt="xyxy"))
-    if name == "v3":
-        return dict(body=v3_body,
+    if name in ("v3", "v4"):
+        return dict(body=v3_body if name == "v3" else v4_body,
                     decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "v3"),
                     nms=dict(in_fmt="cxcywh"))
     raise KeyError(name)

@@ -17,7 +17,7 @@ from test_gpu_v5_e2e import _check_pred, _match_rows, _rel_l2
 
 pytestmark = pytest.mark.gpu
 
-NAMES = ["v8s", "v3"]
+NAMES = ["v8s", "v3", "v4"]
 EXP_WH = ("v3", "v4")
 
 

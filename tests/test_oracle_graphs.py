@@ -11,7 +11,7 @@ from oracle import graphs_ref, postprocess
 from yolo_amd import models
 from yolo_amd.init import seeded_images, seeded_state_dict
 
-NAMES = ["v8s", "v3"]
+NAMES = ["v8s", "v3", "v4"]
 
 
 def _setup(name, which):
@@ -59,3 +59,24 @@ def test_full_size_subsampled_rows(name):
     np.testing.assert_allclose(raws[-1], g["raw_last"], rtol=1e-4, atol=3e-4)
     pred = ref["decode"](raws, p, False)
     np.testing.assert_allclose(pred[:, g["pred_rows"]], g["pred"], rtol=1e-4, atol=2e-3)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_fuse_matches_reference_fuse(name):
+    """fuse() leaves the reference's fused checkpoint layout; the oracle graph run on it reproduces the
+    reference's post-fuse outputs.  Models whose reference fuse() raises (v3, v8) must raise here too."""
+    g, p, model, sd, imgs = _setup(name, "small")
+    if "fused_n_keys" not in g:
+        with pytest.raises(NotImplementedError):
+            model.fuse()
+        return
+    model.load_state_dict(sd, strict=True)
+    model.fuse()
+    fs = model.state_dict()
+    assert len(fs) == int(g["fused_n_keys"])
+    for k in g["fused_bias_keys"]:
+        assert str(k) in fs
+    ref = graphs_ref.model_ref(name)
+    with torch.no_grad():
+        raws = [t.numpy() for t in ref["body"](fs, imgs)]
+    np.testing.assert_allclose(ref["decode"](raws, p, False), g["fused_pred"], rtol=1e-4, atol=2e-4)

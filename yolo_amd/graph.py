@@ -93,6 +93,11 @@ class TaskModel(nn.Module):
                 delattr(m, bn_name)
         self.invalidate()
 
+    def fuse(self):
+        """Models without a re-parameterisation step in the reference raise there too (model/Layer.py TaskLayer.fuse);
+        BatchNorm is folded when the plan is compiled, so callers have nothing to do."""
+        raise NotImplementedError(f"{type(self).__name__}.fuse is not implemented in the reference")
+
     def to_onnx(self, onnx_path: str):
         raise NotImplementedError("ONNX export is outside the accelerated path; use the reference for export")
 

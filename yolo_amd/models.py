@@ -7,6 +7,7 @@ from . import param as _param
 
 def registry() -> Dict[str, Dict[str, Any]]:
     from .yolov3 import YoloV3
+    from .yolov4 import YoloV4
     from .yolov5 import YoloV5
     from .yolov8 import YoloV8
     return {
@@ -16,6 +17,9 @@ def registry() -> Dict[str, Dict[str, Any]]:
         # head convs so that the logits (w,h go through exp) have a std of 1-2
         "v3": dict(cls=YoloV3, param=lambda: _param.Yolo3Param().set_img_size(608),
                    init=dict(scale={".conv.3.weight": 0.25, ".6.weight": 0.05})),
+        "v4": dict(cls=YoloV4, param=lambda: _param.Yolo4Param().set_img_size(608),
+                   init=dict(scale={".block.1.conv.weight": 0.25, "yolo_head1.1.weight": 0.05,
+                                    "yolo_head2.1.weight": 0.05, "yolo_head3.1.weight": 0.05})),
     }
 
 

@@ -187,8 +187,3 @@ class YoloV8(TaskModel):
                                                   self.param.nms_threshold)
         tensor_dict["predicts"] = torch_utils.rows_to_host(rows, counts)
         return tensor_dict
-
-    def fuse(self):
-        """The reference's YoloV8.fuse raises (YoloV8.py:161-162); BatchNorm is folded when the plan is
-        compiled, so there is nothing for the caller to do."""
-        raise NotImplementedError("YoloV8.fuse is not implemented in the reference; BN is folded at plan compile time")
