@@ -271,6 +271,7 @@ def _ref_models():
         "v8s": (YoloV8, lambda: Yolo8Param(m_type="s"), "asc", 7, 64),
         "v3": (YoloV3, lambda: Yolo3Param(), "desc", 7, 64),
         "v4": (YoloV4, lambda: Yolo4Param(), "desc", 7, 64),
+        "v7pose": (YoloV7Pose, lambda: Yolo7PoseParam(m_type="l"), "desc", 6 + 3 * 17 + 1, 64),
     }
 
 

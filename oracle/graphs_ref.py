@@ -181,6 +181,73 @@ def v4_body(sd: SD, images: torch.Tensor) -> List[torch.Tensor]:
 
 
 # ------------------------------------------------------------------------------------------------
+# YOLOv7 pose: luoyang/yolov7_pose/YoloV7PoseBody.py Conv :24-48 (BN eps 1e-3, SiLU), MultiConcatBlock :51-73,
+# TransitionBlock :85-100, Backbone.forward :131-148, SppCspC :175-192, RepConv.forward :247-254 (three branches,
+# or the single rbr_reparam conv after fuse), YoloV7PoseBody.forward :479-509
+# ------------------------------------------------------------------------------------------------
+def _v7_conv(sd, p, x, s=1):
+    return conv_bn_act(sd, p + ".conv", p + ".bn", x, s, silu, 1e-3)
+
+
+def _v7_mcb(sd, p, x, ids):
+    xs = [_v7_conv(sd, p + ".cv1", x), _v7_conv(sd, p + ".cv2", x)]
+    for i in range(_count(sd, p + ".cv3.{}.conv.weight")):
+        xs.append(_v7_conv(sd, f"{p}.cv3.{i}", xs[-1]))
+    return _v7_conv(sd, p + ".cv4", torch.cat([xs[i] for i in ids], 1))
+
+
+def _v7_transition(sd, p, x):
+    x1 = _v7_conv(sd, p + ".cv1", F.max_pool2d(x, 2, 2))
+    x2 = _v7_conv(sd, p + ".cv3", _v7_conv(sd, p + ".cv2", x), 2)
+    return torch.cat((x2, x1), 1)
+
+
+def _v7_rep(sd, p, x):
+    if p + ".rbr_reparam.weight" in sd:
+        return silu(F.conv2d(x, sd[p + ".rbr_reparam.weight"], sd[p + ".rbr_reparam.bias"], padding=1))
+    if p + ".conv.weight" in sd:                         # the 'x' variant uses a plain Conv here
+        return _v7_conv(sd, p, x)
+
+    def bn(y, q):
+        return F.batch_norm(y, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"],
+                            False, 0.0, 1e-3)
+    y = bn(F.conv2d(x, sd[p + ".rbr_dense.0.weight"], padding=1), p + ".rbr_dense.1")
+    y = y + bn(F.conv2d(x, sd[p + ".rbr_1x1.0.weight"]), p + ".rbr_1x1.1")
+    if p + ".rbr_identity.weight" in sd:
+        y = y + bn(x, p + ".rbr_identity")
+    return silu(y)
+
+
+def v7pose_body(sd: SD, images: torch.Tensor, phi: str = "l") -> List[torch.Tensor]:
+    """images (B,3,S,S) -> raw heads [stride 8, 16, 32], each (B, 3*(5+3P+nc), h, w)."""
+    bids = {"l": [-1, -3, -5, -6], "x": [-1, -3, -5, -7, -8]}[phi]
+    nids = {"l": [-1, -2, -3, -4, -5, -6], "x": [-1, -3, -5, -7, -8]}[phi]
+    b, n = "body_net.backbone.", "body_net."
+    x = _v7_conv(sd, b + "stem.2", _v7_conv(sd, b + "stem.1", _v7_conv(sd, b + "stem.0", images), 2))
+    x = _v7_mcb(sd, b + "dark2.1", _v7_conv(sd, b + "dark2.0", x, 2), bids)
+    feat1 = _v7_mcb(sd, b + "dark3.1", _v7_transition(sd, b + "dark3.0", x), bids)
+    feat2 = _v7_mcb(sd, b + "dark4.1", _v7_transition(sd, b + "dark4.0", feat1), bids)
+    feat3 = _v7_mcb(sd, b + "dark5.1", _v7_transition(sd, b + "dark5.0", feat2), bids)
+    sp = n + "spp_csp_c"
+    x1 = _v7_conv(sd, sp + ".cv4", _v7_conv(sd, sp + ".cv3", _v7_conv(sd, sp + ".cv1", feat3)))
+    y1 = torch.cat([x1] + [F.max_pool2d(x1, k, 1, k // 2) for k in (5, 9, 13)], 1)
+    y1 = _v7_conv(sd, sp + ".cv6", _v7_conv(sd, sp + ".cv5", y1))
+    p5 = _v7_conv(sd, sp + ".cv7", torch.cat((y1, _v7_conv(sd, sp + ".cv2", feat3)), 1))
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest")
+    p4 = torch.cat((_v7_conv(sd, n + "conv_for_feat2", feat2), up(_v7_conv(sd, n + "conv_for_P5", p5))), 1)
+    p4 = _v7_mcb(sd, n + "conv3_for_up_sample1", p4, nids)
+    p3 = torch.cat((_v7_conv(sd, n + "conv_for_feat1", feat1), up(_v7_conv(sd, n + "conv_for_P4", p4))), 1)
+    p3 = _v7_mcb(sd, n + "conv3_for_up_sample2", p3, nids)
+    p4 = _v7_mcb(sd, n + "conv3_for_down_sample1", torch.cat((_v7_transition(sd, n + "down_sample1", p3), p4), 1), nids)
+    p5 = _v7_mcb(sd, n + "conv3_for_down_sample2", torch.cat((_v7_transition(sd, n + "down_sample2", p4), p5), 1), nids)
+    outs = []
+    for rep, head, t in (("rep_conv_1", "yolo_head_P3", p3), ("rep_conv_2", "yolo_head_P4", p4),
+                         ("rep_conv_3", "yolo_head_P5", p5)):
+        outs.append(F.conv2d(_v7_rep(sd, n + rep, t), sd[n + head + ".weight"], sd[n + head + ".bias"]))
+    return outs
+
+
+# ------------------------------------------------------------------------------------------------
 # per-model glue: body graph, decode of its raw heads, NMS flavour of its predict()
 # ------------------------------------------------------------------------------------------------
 def model_ref(name: str):
@@ -200,4 +267,9 @@ def model_ref(name: str):
         return dict(body=v3_body if name == "v3" else v4_body,
                     decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "v3"),
                     nms=dict(in_fmt="cxcywh"))
+    if name == "v7pose":
+        return dict(body=v7pose_body,
+                    decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "pose",
+                                                                             point_num=p.point_num, clamp_points=predict),
+                    nms=dict(in_fmt="cxcywh", point_num=17, point_conf=True))
     raise KeyError(name)

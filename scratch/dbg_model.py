@@ -22,3 +22,12 @@ bad = np.argwhere(d[..., :4] > tol)
 print(len(bad)); print(bad[:20])
 for b, a, c in bad[:10]:
     print(pred[b, a, :5], w[b, a, :5])
+if w.shape[-1] > 30:
+    P = 17
+    dk = d[..., 5:5 + 2 * P]
+    print("kp max", dk.max(), "mean", dk.mean(), "frac>1px", (dk > 1).mean(), "frac>3px", (dk > 3).mean())
+    ds = d[..., 5 + 2 * P:]
+    print("kpconf/cls max", ds.max(), "frac>2e-2", (ds > 2e-2).mean())
+    lv = np.cumsum([0] + [3 * (size // s) ** 2 for s in p.strides])
+    for i in range(3):
+        print("level", i, "kp max", dk[:, lv[i]:lv[i + 1]].max(), "mean", dk[:, lv[i]:lv[i + 1]].mean())

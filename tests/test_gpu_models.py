@@ -17,8 +17,9 @@ from test_gpu_v5_e2e import _check_pred, _match_rows, _rel_l2
 
 pytestmark = pytest.mark.gpu
 
-NAMES = ["v8s", "v3", "v4"]
+NAMES = ["v8s", "v3", "v4", "v7pose"]
 EXP_WH = ("v3", "v4")
+POINTS = {"v7pose": 17}
 
 
 def _model(name, size, seed):
@@ -43,7 +44,7 @@ def test_small_vs_reference_golden(name, gpu_device):
         assert _rel_l2(got, g[f"raw{i}"]) <= 3e-2, (i, _rel_l2(got, g[f"raw{i}"]))
     pred = m._forward(imgs)[0].cpu().numpy()
     assert pred.shape == g["pred"].shape
-    _check_pred(pred, g["pred"], size, name in EXP_WH)
+    _check_pred(pred, g["pred"], size, name in EXP_WH, POINTS.get(name, 0))
     out = m.predict({"batch_images": imgs})["predicts"]
     want = split_rows(g["counts"], g["rows"])
     for a, b in zip(out, want):
@@ -74,8 +75,8 @@ def test_full_size_vs_oracle_graph(name, gpu_device):
     for i, (got, want) in enumerate(zip(raws, want_raws)):
         assert _rel_l2(got, want) <= 3e-2, (i, _rel_l2(got, want))
     pred = m._forward(imgs)[0].cpu().numpy()
-    _check_pred(pred, ref["decode"](want_raws, p, False), size, name in EXP_WH)
-    _check_pred(pred[:1, g["pred_rows"]], g["pred"], size, name in EXP_WH)
+    _check_pred(pred, ref["decode"](want_raws, p, False), size, name in EXP_WH, POINTS.get(name, 0))
+    _check_pred(pred[:1, g["pred_rows"]], g["pred"], size, name in EXP_WH, POINTS.get(name, 0))
 
 
 def test_v8_feed_forward_keys(gpu_device):
@@ -92,3 +93,17 @@ def test_v8_feed_forward_keys(gpu_device):
     boxes = (td["predict_scaled_bounding_boxes"] * td["stride_tensor"]).cpu().numpy()
     pred = m._decode(m.raw_heads(imgs), "xyxy").cpu().numpy()
     assert np.array_equal(boxes, pred[..., :4])
+
+
+@pytest.mark.parametrize("name", ["v4", "v7pose"])
+def test_fused_equals_unfused(name, gpu_device):
+    """fuse() (BN folding, RepConv re-parameterisation) changes the checkpoint layout, not the outputs"""
+    from yolo_amd.init import seeded_images
+    p, m, _ = _model(name, 64, 31)
+    imgs = torch.from_numpy(seeded_images(2, 64, seed=31)).to(gpu_device)
+    a = m._forward(imgs)[0].cpu().numpy()
+    n_before = len(m.state_dict())
+    m.fuse()
+    assert len(m.state_dict()) < n_before
+    b = m._forward(imgs)[0].cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3)

@@ -30,12 +30,18 @@ def _rel_l2(a, b):
     return float(np.linalg.norm((a - b).astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
 
 
-def _check_pred(got, want, img, exp_wh=False):
+def _check_pred(got, want, img, exp_wh=False, point_num=0):
     box_tol = 0.5 + 0.01 * np.abs(want[..., :4])
     if exp_wh:   # v3/v4: w,h = exp(t)*anchor turns the absolute bf16 error of the logit t into a relative size error
         box_tol[..., 2:4] = 0.5 + 0.05 * np.abs(want[..., 2:4])
     bad = np.abs(got[..., :4] - want[..., :4]) > box_tol
     assert bad.mean() < 2e-3, f"box mismatch fraction {bad.mean()}"
+    if point_num:   # keypoint / landmark coordinates (pixels) sit between obj and the confidences: box tolerance
+        k0, k1 = 5, 5 + 2 * point_num
+        badp = np.abs(got[..., k0:k1] - want[..., k0:k1]) > 0.5 + 0.01 * np.abs(want[..., k0:k1])
+        assert badp.mean() < 2e-3, f"keypoint mismatch fraction {badp.mean()}"
+        got = np.concatenate((got[..., :k0], got[..., k1:]), -1)
+        want = np.concatenate((want[..., :k0], want[..., k1:]), -1)
     ds = np.abs(got[..., 4:] - want[..., 4:])
     assert (ds > 2e-2).mean() < 2e-3, f"score mismatch fraction {(ds > 2e-2).mean()}, max {ds.max()}"
 
@@ -46,7 +52,7 @@ def _match_rows(got, want, iou_thr=0.9):
         return 1.0 if (want is None and got is None) else 0.0
     hit = 0
     for r in want:
-        same = got[got[:, 6] == r[6]]
+        same = got[got[:, -1] == r[-1]]
         if same.shape[0] == 0:
             continue
         x1 = np.maximum(same[:, 0], r[0]); y1 = np.maximum(same[:, 1], r[1])

@@ -22,13 +22,14 @@ def seeded_state_dict(model: torch.nn.Module, seed: int = 0, mode: str = "spread
     of every residual branch so that a deep residual stack keeps its activation range)."""
     rng = np.random.RandomState(seed)
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    bn_prefixes = {n + "." for n, m in model.named_modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)}
     for name, ref in model.state_dict().items():
         shape = tuple(ref.shape)
         leaf = name.rsplit(".", 1)[-1]
         if leaf == "num_batches_tracked":
             out[name] = torch.zeros((), dtype=torch.long)
             continue
-        is_bn = ".bn." in name or (len(shape) == 1 and leaf in ("running_mean", "running_var"))
+        is_bn = name[:len(name) - len(leaf)] in bn_prefixes
         if len(shape) == 4:                                        # conv weight
             fan_in = shape[1] * shape[2] * shape[3]
             if mode == "spread":

@@ -9,6 +9,7 @@ def registry() -> Dict[str, Dict[str, Any]]:
     from .yolov3 import YoloV3
     from .yolov4 import YoloV4
     from .yolov5 import YoloV5
+    from .yolov7_pose import YoloV7Pose
     from .yolov8 import YoloV8
     return {
         "v5s": dict(cls=YoloV5, param=lambda: _param.Yolo5Param(m_type="s").set_img_size(640), init={}),
@@ -20,6 +21,7 @@ def registry() -> Dict[str, Dict[str, Any]]:
         "v4": dict(cls=YoloV4, param=lambda: _param.Yolo4Param().set_img_size(608),
                    init=dict(scale={".block.1.conv.weight": 0.25, "yolo_head1.1.weight": 0.05,
                                     "yolo_head2.1.weight": 0.05, "yolo_head3.1.weight": 0.05})),
+        "v7pose": dict(cls=YoloV7Pose, param=lambda: _param.Yolo7PoseParam(m_type="l"), init={}),
     }
 
 
