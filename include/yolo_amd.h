@@ -97,6 +97,11 @@ int yamd_maxpool5_cascade(const void *x, int x_cstride, void *y1, void *y2, void
  * x (batch,h,w,c) -> y (batch,h/2,w/2,c); h, w even, c % 8 == 0. */
 int yamd_maxpool2(const void *x, int x_cstride, void *y, int y_cstride, int batch, int h, int w, int c,
                   void *stream);
+/* Second half of nn.ConvTranspose2d(kernel 2, stride 2) (yolov6_face/YoloV6FaceBody.py:475-492): the transposed
+ * conv is run as a 1x1 conv to 4*c channels ordered (dy, dx, c); this scatters x (batch,h,w,4c) to
+ * y (batch,2h,2w,c) with y[b,2i+dy,2j+dx,:] = x[b,i,j,(2dy+dx)*c : (2dy+dx+1)*c].  c % 8 == 0. */
+int yamd_depth_to_space2(const void *x, int x_cstride, void *y, int y_cstride, int batch, int h, int w, int c,
+                         void *stream);
 /* Channel-slice copy (batch*h*w pixels, c channels, c % 8 == 0): torch.cat when a producer could
  * not write its slice in place. */
 int yamd_copy_channels(const void *x, int x_cstride, void *y, int y_cstride, long long pixels, int c,
@@ -129,6 +134,15 @@ int yamd_decode_anchor(int kind, const float *raw, int batch, int h, int w, int 
 int yamd_decode_dfl(const float *const *raw_host_ptrs, const int *hs_host, const int *ws_host,
                     const int *strides_host, int n_levels, int batch, int reg_max, int nc, int out_cxcywh,
                     float *out, void *stream);
+
+/* Anchor-free decode without DFL plus landmarks, all levels in one call (yolov6_face/YoloV6FaceBody.py:1354-1397
+ * bbox_decode/point_decode and :1439-1455, assembled by yolov6_face/YoloV6Face.py:42-58 and :60-74).
+ * raw[i]: (batch,h_i,w_i,4+2*point_num+nc) float NHWC, channel order [l,t,r,b | x0,y0,x1,y1.. | cls nc].
+ * out: (batch, sum h_i*w_i, 5+2*point_num+nc) = [box, 1.0, landmarks (pixels), sigmoid(cls)]; box xyxy
+ * (out_cxcywh=0, predict form) or cxcywh (1, _forward form), input pixels. */
+int yamd_decode_ltrb_points(const float *const *raw_host_ptrs, const int *hs_host, const int *ws_host,
+                            const int *strides_host, int n_levels, int batch, int point_num, int nc, int out_cxcywh,
+                            float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Confidence filter + per-class greedy NMS for a whole batch; replaces the Python per-image loop

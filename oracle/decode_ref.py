@@ -142,3 +142,31 @@ def decode_dfl(raws: List[np.ndarray], strides: Sequence[int], reg_max: int, num
     sc = _sigmoid(cls)
     conf = sc.max(axis=-1, keepdims=True)
     return np.concatenate((box, conf, sc), -1).astype(F32)
+
+
+def decode_ltrb_points(raws: List[np.ndarray], strides: Sequence[int], point_num: int, num_classes: int,
+                       out_fmt: str) -> np.ndarray:
+    """v6 face without DFL (luoyang/yolov6_face/YoloV6FaceBody.py:1354-1397, :1439-1455; assembled by
+    luoyang/yolov6_face/YoloV6Face.py:42-58 / :66-74): raws[i] (B, 4+2P+nc, H, W) in the order [ltrb | landmarks | cls]
+    -> (B, A, 5+2P+nc) = [box, 1.0, landmarks, sigmoid(cls)]; box xyxy (predict) or cxcywh (_forward), pixels."""
+    outs = []
+    for raw, s in zip(raws, strides):
+        B, ch, H, W = raw.shape
+        t = raw.astype(F32).reshape(B, ch, H * W).transpose(0, 2, 1)
+        fs = F32(s)
+        ys, xs = np.meshgrid(np.arange(H, dtype=F32), np.arange(W, dtype=F32), indexing="ij")
+        ax = (((xs.reshape(-1) + F32(0.5)) * fs) / fs).astype(F32)
+        ay = (((ys.reshape(-1) + F32(0.5)) * fs) / fs).astype(F32)
+        x1, y1 = (ax - t[..., 0]) * fs, (ay - t[..., 1]) * fs
+        x2, y2 = (ax + t[..., 2]) * fs, (ay + t[..., 3]) * fs
+        o = np.empty((B, H * W, 5 + 2 * point_num + num_classes), F32)
+        if out_fmt == "cxcywh":
+            o[..., 0], o[..., 1], o[..., 2], o[..., 3] = (x1 + x2) / F32(2), (y1 + y2) / F32(2), x2 - x1, y2 - y1
+        else:
+            o[..., 0], o[..., 1], o[..., 2], o[..., 3] = x1, y1, x2, y2
+        o[..., 4] = 1.0
+        for k in range(2 * point_num):
+            o[..., 5 + k] = (t[..., 4 + k] + (ay if k & 1 else ax)) * fs
+        o[..., 5 + 2 * point_num:] = _sigmoid(t[..., 4 + 2 * point_num:])
+        outs.append(o)
+    return np.concatenate(outs, 1)

@@ -20,12 +20,13 @@ from oracle import ref_harness  # noqa: E402
 
 ref_harness.install()
 
-from luoyang.param.Param import Yolo3Param, Yolo4Param, Yolo5Param, Yolo7FaceParam, Yolo7PoseParam, Yolo8Param  # noqa: E402
+from luoyang.param.Param import Yolo6FaceParam, Yolo3Param, Yolo4Param, Yolo5Param, Yolo7FaceParam, Yolo7PoseParam, Yolo8Param  # noqa: E402
 from luoyang.utils import torch_utils as ref_tu  # noqa: E402
 from luoyang.yolov3.YoloHead import YoloHead  # noqa: E402
 from luoyang.yolov3.YoloV3 import YoloV3  # noqa: E402
 from luoyang.yolov4.YoloV4 import YoloV4  # noqa: E402
 from luoyang.yolov5.YoloV5 import YoloV5  # noqa: E402
+from luoyang.yolov6_face.YoloV6Face import YoloV6Face  # noqa: E402
 from luoyang.yolov5.YoloV5Head import YoloV5Head  # noqa: E402
 from luoyang.yolov7_face.YoloV7FaceHead import YoloV7FaceHead  # noqa: E402
 from luoyang.yolov7_pose.YoloV7Pose import YoloV7Pose  # noqa: E402
@@ -272,7 +273,22 @@ def _ref_models():
         "v3": (YoloV3, lambda: Yolo3Param(), "desc", 7, 64),
         "v4": (YoloV4, lambda: Yolo4Param(), "desc", 7, 64),
         "v7pose": (YoloV7Pose, lambda: Yolo7PoseParam(m_type="l"), "desc", 6 + 3 * 17 + 1, 64),
+        "v6face": (YoloV6Face, lambda: Yolo6FaceParam(m_type="s"), "v6", 6 + 2 * 5 + 1, 128),
     }
+
+
+def _v6_raw_heads(model, imgs):
+    """The per-level logits of the reference's YoloV6FaceHead (its own sub-modules, called in the order of
+    YoloV6FaceBody.py:1403-1418), concatenated as [ltrb | landmarks | cls]."""
+    hd = model.yolo_body.head
+    outs = []
+    for i, f in enumerate(model.yolo_body(imgs)):
+        s = hd.stems[i](f)
+        reg = hd.reg_predict_list[i](hd.reg_conv_list[i](s))
+        pts = hd.reg_point_predict_list[i](hd.reg_point_conv_list[i](s))
+        cls = hd.cls_predict_list[i](hd.cls_conv_list[i](s))
+        outs.append(torch.cat((reg, pts, cls), 1))
+    return outs
 
 
 def gen_model(name):
@@ -293,7 +309,10 @@ def gen_model(name):
         model.load_state_dict(sd, strict=True)
         imgs = torch.from_numpy(seeded_images(batch, size, seed=seed))
         with torch.no_grad():
-            raws = list(model.body_net(imgs))
+            if order == "v6":
+                raws = _v6_raw_heads(model, imgs)
+            else:
+                raws = list(model.body_net(imgs))
             if order == "desc":
                 raws = raws[::-1]
             pred = model._forward(imgs)[0]

@@ -248,6 +248,99 @@ def v7pose_body(sd: SD, images: torch.Tensor, phi: str = "l") -> List[torch.Tens
 
 
 # ------------------------------------------------------------------------------------------------
+# YOLOv6 face (n/s): luoyang/yolov6_face/YoloV6FaceBody.py ConvModule :98-134, RepVGGBlock.forward :187-200 (ReLU over
+# the sum of the 3x3, 1x1 and identity-BN branches, or the deployed rbr_re_param conv), CSPSPPFModule :372-396,
+# RepBlock :427-448, Transpose :475-492, EfficientRep6.forward :572-586, BiFusion.forward :605-609,
+# RepBiFPANNeck6.forward :688-716, YoloV6FaceHead.forward :1399-1437 (per-level convs); all BN eps 1e-3 (:1479-1486)
+# ------------------------------------------------------------------------------------------------
+def _v6_cm(sd, p, x, s, act, pad=None):
+    w = sd[p + ".conv.weight"]
+    k = w.shape[-1]
+    y = F.conv2d(x, w, sd.get(p + ".conv.bias"), stride=s, padding=k // 2 if pad is None else pad)
+    if p + ".bn.weight" in sd:
+        y = F.batch_norm(y, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], sd[p + ".bn.weight"],
+                         sd[p + ".bn.bias"], False, 0.0, 1e-3)
+    return y if act is None else act(y)
+
+
+def _v6_rep(sd, p, x, s=1):
+    if p + ".rbr_re_param.weight" in sd:
+        return F.relu(F.conv2d(x, sd[p + ".rbr_re_param.weight"], sd[p + ".rbr_re_param.bias"], stride=s, padding=1))
+    y = _v6_cm(sd, p + ".rbr_dense", x, s, None) + _v6_cm(sd, p + ".rbr_1x1", x, s, None, pad=0)
+    q = p + ".rbr_identity"
+    if q + ".weight" in sd:
+        y = y + F.batch_norm(x, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"],
+                             False, 0.0, 1e-3)
+    return F.relu(y)
+
+
+def _v6_is_rep(sd, p):
+    return (p + ".rbr_dense.conv.weight") in sd or (p + ".rbr_re_param.weight") in sd
+
+
+def _v6_repblock(sd, p, x):
+    x = _v6_rep(sd, p + ".conv1", x)
+    i = 0
+    while _v6_is_rep(sd, f"{p}.block.{i}"):
+        x = _v6_rep(sd, f"{p}.block.{i}", x)
+        i += 1
+    return x
+
+
+def _v6_w(sd, p, x, s=1, act=F.relu):
+    return _v6_cm(sd, p + ".block", x, s, act)
+
+
+def _v6_bifusion(sd, p, xs):
+    x0 = F.conv_transpose2d(xs[0], sd[p + ".up_sample.up_sample_transpose.weight"],
+                            sd[p + ".up_sample.up_sample_transpose.bias"], stride=2)
+    x1 = _v6_w(sd, p + ".cv1", xs[1])
+    x2 = _v6_w(sd, p + ".down_sample", _v6_w(sd, p + ".cv2", xs[2]), 2)
+    return _v6_w(sd, p + ".cv3", torch.cat((x0, x1, x2), 1))
+
+
+def v6face_body(sd: SD, images: torch.Tensor) -> List[torch.Tensor]:
+    """images (B,3,S,S) -> per level (stride 8, 16, 32, 64) raw head logits (B, 4+2P+nc, h, w) in the channel
+    order [ltrb | landmarks | cls]."""
+    b, n, h = "yolo_body.back_bone_network.", "yolo_body.neck_network.", "yolo_body.head."
+    x = _v6_rep(sd, b + "stem", images, 2)
+    feats = []
+    for i in range(2, 7):
+        x = _v6_repblock(sd, f"{b}ERBlock_{i}.1", _v6_rep(sd, f"{b}ERBlock_{i}.0", x, 2))
+        if i == 6:
+            sp = f"{b}ERBlock_6.2.cspsppf"
+            x1 = _v6_w(sd, sp + ".cv4", _v6_w(sd, sp + ".cv3", _v6_w(sd, sp + ".cv1", x)))
+            y0 = _v6_w(sd, sp + ".cv2", x)
+            y1 = F.max_pool2d(x1, 5, 1, 2)
+            y2 = F.max_pool2d(y1, 5, 1, 2)
+            y3 = _v6_w(sd, sp + ".cv6", _v6_w(sd, sp + ".cv5", torch.cat((x1, y1, y2, F.max_pool2d(y2, 5, 1, 2)), 1)))
+            x = _v6_w(sd, sp + ".cv7", torch.cat((y0, y3), 1))
+        feats.append(x)
+    x4, x3, x2, x1, x0 = feats
+    fpn0 = _v6_w(sd, n + "reduce_layer0", x0)
+    f0 = _v6_repblock(sd, n + "Rep_p5", _v6_bifusion(sd, n + "Bi_fusion_0", [fpn0, x1, x2]))
+    fpn1 = _v6_w(sd, n + "reduce_layer1", f0)
+    f1 = _v6_repblock(sd, n + "Rep_p4", _v6_bifusion(sd, n + "Bi_fusion_1", [fpn1, x2, x3]))
+    fpn2 = _v6_w(sd, n + "reduce_layer2", f1)
+    pan3 = _v6_repblock(sd, n + "Rep_p3", _v6_bifusion(sd, n + "Bi_fusion_2", [fpn2, x3, x4]))
+    pan2 = _v6_repblock(sd, n + "Rep_n4", torch.cat((_v6_w(sd, n + "down_sample_2", pan3, 2), fpn2), 1))
+    pan1 = _v6_repblock(sd, n + "Rep_n5", torch.cat((_v6_w(sd, n + "down_sample_1", pan2, 2), fpn1), 1))
+    pan0 = _v6_repblock(sd, n + "Rep_n6", torch.cat((_v6_w(sd, n + "down_sample_0", pan1, 2), fpn0), 1))
+    outs = []
+    for i, t in enumerate((pan3, pan2, pan1, pan0)):
+        if f"{h}stems.{i}.block.conv.weight" not in sd:
+            break
+        s_ = _v6_w(sd, f"{h}stems.{i}", t, 1, silu)
+
+        def pred(conv_list, pred_list):
+            f = _v6_w(sd, f"{h}{conv_list}.{i}", s_, 1, silu)
+            return F.conv2d(f, sd[f"{h}{pred_list}.{i}.weight"], sd[f"{h}{pred_list}.{i}.bias"])
+        outs.append(torch.cat((pred("reg_conv_list", "reg_predict_list"), pred("reg_point_conv_list", "reg_point_predict_list"),
+                               pred("cls_conv_list", "cls_predict_list")), 1))
+    return outs
+
+
+# ------------------------------------------------------------------------------------------------
 # per-model glue: body graph, decode of its raw heads, NMS flavour of its predict()
 # ------------------------------------------------------------------------------------------------
 def model_ref(name: str):
@@ -272,4 +365,9 @@ def model_ref(name: str):
                     decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "pose",
                                                                              point_num=p.point_num, clamp_points=predict),
                     nms=dict(in_fmt="cxcywh", point_num=17, point_conf=True))
+    if name == "v6face":
+        return dict(body=v6face_body,
+                    decode=lambda raws, p, predict: decode_ref.decode_ltrb_points(raws, p.strides, p.point_num, p.class_num,
+                                                                                  "xyxy" if predict else "cxcywh"),
+                    nms=dict(in_fmt="xyxy", point_num=5, point_conf=False))
     raise KeyError(name)

@@ -175,3 +175,37 @@ def test_upsample_copy_maxpool(gpu_device):
     for i, k in enumerate((5, 9, 13)):
         want = F.max_pool2d(s, k, 1, k // 2).permute(0, 2, 3, 1).to(torch.bfloat16)
         assert torch.equal(got[..., (i + 1) * c:(i + 2) * c], want), f"pool {k}"
+
+
+def test_maxpool2_and_conv_transpose(gpu_device):
+    """MaxPool2d(2,2) exact; ConvTranspose2d(2,2)+bias = 1x1 conv to 4c channels + depth-to-space, through the
+    engine ops, against torch fp32 on bf16-rounded operands (rel L2 <= 1e-2: one bf16 rounding of the output)."""
+    from yolo_amd import lib as L
+    from yolo_amd.engine import Program
+    st = L.current_stream()
+    x = torch.randn(2, 6, 10, 24).to(torch.bfloat16)
+    xd = x.to(gpu_device)
+    y = torch.zeros((2, 3, 5, 32), dtype=torch.bfloat16, device=gpu_device)
+    L.check(L.LIB.yamd_maxpool2(xd.data_ptr() + 8 * 2, 24, y.data_ptr() + 8 * 2, 32, 2, 6, 10, 16, st))
+    torch.cuda.synchronize()
+    want = F.max_pool2d(x[..., 8:24].float().permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).to(torch.bfloat16)
+    got = y.cpu()
+    assert torch.equal(got[..., 8:24], want) and torch.all(got[..., :8] == 0) and torch.all(got[..., 24:] == 0)
+
+    # transposed conv through a tiny program: image16 -> 3x3 conv to 32 ch -> ConvTranspose2d(32, 32, 2, 2)
+    torch.manual_seed(3)
+    P = Program(16, 24)
+    w0 = torch.randn(32, 3, 3, 3) * 0.3
+    wt = torch.randn(32, 32, 2, 2) * 0.2
+    bt = torch.randn(32)
+    a = P.conv("c0", P.image16(3), w0, None, 1, L.ACT_NONE)
+    P.outputs["a"] = a
+    P.outputs["up"] = P.conv_transpose2x("t", a, wt, bt)
+    img = torch.rand(2, 3, 16, 24)
+    out = P.run(img.to(gpu_device))
+    av = out["a"].float().cpu().permute(0, 3, 1, 2)                      # the bf16 activations the GPU fed forward
+    want = F.conv_transpose2d(av, _bf16_round(wt), bt, stride=2)
+    got = out["up"].float().cpu().permute(0, 3, 1, 2)
+    assert got.shape == want.shape
+    rel = torch.linalg.norm(got - want) / torch.linalg.norm(want)
+    assert rel <= 1e-2, float(rel)

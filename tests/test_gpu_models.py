@@ -17,9 +17,26 @@ from test_gpu_v5_e2e import _check_pred, _match_rows, _rel_l2
 
 pytestmark = pytest.mark.gpu
 
-NAMES = ["v8s", "v3", "v4", "v7pose"]
+NAMES = ["v8s", "v3", "v4", "v7pose", "v6face"]
 EXP_WH = ("v3", "v4")
-POINTS = {"v7pose": 17}
+POINTS = {"v7pose": 17, "v6face": 5}
+
+
+def _row_stride(name, p, size):
+    if name != "v6face":
+        return None
+    return np.concatenate([np.full((size // s) ** 2, s, np.float32) for s in p.strides])
+
+
+def _match_rows_abs(got, want, tol):
+    """fraction of reference rows with a same-class detection whose four box coordinates all lie within tol px
+    (used where random-init boxes are degenerate -- negative or sub-pixel sizes -- and IoU is meaningless)"""
+    hit = 0
+    for r in want:
+        same = got[got[:, -1] == r[-1]]
+        if same.shape[0] and np.abs(same[:, :4] - r[:4]).max(1).min() <= tol:
+            hit += 1
+    return hit / want.shape[0]
 
 
 def _model(name, size, seed):
@@ -44,7 +61,7 @@ def test_small_vs_reference_golden(name, gpu_device):
         assert _rel_l2(got, g[f"raw{i}"]) <= 3e-2, (i, _rel_l2(got, g[f"raw{i}"]))
     pred = m._forward(imgs)[0].cpu().numpy()
     assert pred.shape == g["pred"].shape
-    _check_pred(pred, g["pred"], size, name in EXP_WH, POINTS.get(name, 0))
+    _check_pred(pred, g["pred"], size, name in EXP_WH, POINTS.get(name, 0), _row_stride(name, p, size))
     out = m.predict({"batch_images": imgs})["predicts"]
     want = split_rows(g["counts"], g["rows"])
     for a, b in zip(out, want):
@@ -53,7 +70,10 @@ def test_small_vs_reference_golden(name, gpu_device):
             continue
         assert a is not None and a.shape[1] == b.shape[1] and a.dtype == np.float32
         assert abs(a.shape[0] - b.shape[0]) <= max(3, 0.1 * b.shape[0])
-        assert _match_rows(a, b) >= 0.8
+        if name == "v6face":
+            assert _match_rows_abs(a, b, 3.0) >= 0.8
+        else:
+            assert _match_rows(a, b) >= 0.8
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -75,8 +95,10 @@ def test_full_size_vs_oracle_graph(name, gpu_device):
     for i, (got, want) in enumerate(zip(raws, want_raws)):
         assert _rel_l2(got, want) <= 3e-2, (i, _rel_l2(got, want))
     pred = m._forward(imgs)[0].cpu().numpy()
-    _check_pred(pred, ref["decode"](want_raws, p, False), size, name in EXP_WH, POINTS.get(name, 0))
-    _check_pred(pred[:1, g["pred_rows"]], g["pred"], size, name in EXP_WH, POINTS.get(name, 0))
+    _check_pred(pred, ref["decode"](want_raws, p, False), size, name in EXP_WH, POINTS.get(name, 0), _row_stride(name, p, size))
+    rs = _row_stride(name, p, size)
+    _check_pred(pred[:1, g["pred_rows"]], g["pred"], size, name in EXP_WH, POINTS.get(name, 0),
+                None if rs is None else rs[g["pred_rows"]])
 
 
 def test_v8_feed_forward_keys(gpu_device):
@@ -95,12 +117,13 @@ def test_v8_feed_forward_keys(gpu_device):
     assert np.array_equal(boxes, pred[..., :4])
 
 
-@pytest.mark.parametrize("name", ["v4", "v7pose"])
+@pytest.mark.parametrize("name", ["v4", "v7pose", "v6face"])
 def test_fused_equals_unfused(name, gpu_device):
     """fuse() (BN folding, RepConv re-parameterisation) changes the checkpoint layout, not the outputs"""
     from yolo_amd.init import seeded_images
-    p, m, _ = _model(name, 64, 31)
-    imgs = torch.from_numpy(seeded_images(2, 64, seed=31)).to(gpu_device)
+    size = 128 if name == "v6face" else 64
+    p, m, _ = _model(name, size, 31)
+    imgs = torch.from_numpy(seeded_images(2, size, seed=31)).to(gpu_device)
     a = m._forward(imgs)[0].cpu().numpy()
     n_before = len(m.state_dict())
     m.fuse()

@@ -165,3 +165,18 @@ def test_rows_to_host_packs_like_reference_list(gpu_device):
     got = tu.rows_to_host(rows, counts)
     want = split_rows(G["none_images__counts"], G["none_images__rows"])
     assert got[0] is None and got[2] is None and np.array_equal(got[1], want[1])
+
+
+def test_decode_ltrb_points_vs_oracle(gpu_device):
+    """anchor-free ltrb + landmark decode (v6 face) on N(0,2) logits, four levels incl. an odd-sized one, against
+    the numpy oracle (itself pinned to the reference model by tests/golden/v6face_*.npz)"""
+    from oracle import decode_ref as D
+    from yolo_amd import torch_utils as tu
+    rng = np.random.RandomState(9)
+    sizes, strides, P, nc = [(16, 16), (8, 8), (5, 3), (2, 2)], [8, 16, 32, 64], 5, 1
+    raws = [(rng.standard_normal((3, 4 + 2 * P + nc, h, w)) * 2).astype(np.float32) for h, w in sizes]
+    for fmt in ("xyxy", "cxcywh"):
+        want = D.decode_ltrb_points(raws, strides, P, nc, fmt)
+        got = tu.decode_ltrb_points([_nhwc(r, gpu_device) for r in raws], strides, P, nc, fmt).cpu().numpy()
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)

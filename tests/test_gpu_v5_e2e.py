@@ -30,15 +30,19 @@ def _rel_l2(a, b):
     return float(np.linalg.norm((a - b).astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
 
 
-def _check_pred(got, want, img, exp_wh=False, point_num=0):
+def _check_pred(got, want, img, exp_wh=False, point_num=0, row_stride=None):
+    """row_stride: per-row stride for anchor-free heads whose box and landmark columns are (raw logit) x stride:
+    the bf16 error of the logit (a few 1e-2 grid cells) scales with the stride, so 4 % of a cell is added."""
     box_tol = 0.5 + 0.01 * np.abs(want[..., :4])
+    extra = 0.0 if row_stride is None else 0.04 * np.asarray(row_stride, np.float32)[None, :, None]
+    box_tol = box_tol + extra
     if exp_wh:   # v3/v4: w,h = exp(t)*anchor turns the absolute bf16 error of the logit t into a relative size error
         box_tol[..., 2:4] = 0.5 + 0.05 * np.abs(want[..., 2:4])
     bad = np.abs(got[..., :4] - want[..., :4]) > box_tol
     assert bad.mean() < 2e-3, f"box mismatch fraction {bad.mean()}"
     if point_num:   # keypoint / landmark coordinates (pixels) sit between obj and the confidences: box tolerance
         k0, k1 = 5, 5 + 2 * point_num
-        badp = np.abs(got[..., k0:k1] - want[..., k0:k1]) > 0.5 + 0.01 * np.abs(want[..., k0:k1])
+        badp = np.abs(got[..., k0:k1] - want[..., k0:k1]) > 0.5 + 0.01 * np.abs(want[..., k0:k1]) + extra
         assert badp.mean() < 2e-3, f"keypoint mismatch fraction {badp.mean()}"
         got = np.concatenate((got[..., :k0], got[..., k1:]), -1)
         want = np.concatenate((want[..., :k0], want[..., k1:]), -1)

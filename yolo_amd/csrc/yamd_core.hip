@@ -95,6 +95,25 @@ __global__ void upsample2x_kernel(const __bf16 *__restrict__ x, int x_cs, __bf16
     }
 }
 
+// y[b, 2i+di, 2j+dj, c] = x[b, i, j, (2*di+dj)*C + c]
+__global__ void depth_to_space2_kernel(const __bf16 *__restrict__ x, int x_cs, __bf16 *__restrict__ y, int y_cs, int B,
+                                       int H, int W, int C8)
+{
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long total = (long long)B * Ho * Wo * C8;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        const long long pix = i / C8;
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const long long b = pix / ((long long)Wo * Ho);
+        const int blk = 2 * (oy & 1) + (ox & 1);
+        const uint4 v = *(const uint4 *)(x + ((b * H + (oy >> 1)) * W + (ox >> 1)) * x_cs + (blk * C8 + c8) * 8);
+        *(uint4 *)(y + pix * y_cs + c8 * 8) = v;
+    }
+}
+
 __global__ void copy_channels_kernel(const __bf16 *__restrict__ x, int x_cs, __bf16 *__restrict__ y, int y_cs,
                                      long long pixels, int C8)
 {
@@ -214,6 +233,20 @@ extern "C" int yamd_upsample2x(const void *x, int x_cstride, void *y, int y_cstr
                  "upsample needs 16-byte aligned pixels");
     const long long total = (long long)batch * 4 * h * w * (c / 8);
     hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16 *)x, x_cstride, (__bf16 *)y, y_cstride, batch, h, w, c / 8);
+    YAMD_LAUNCH_CHECK();
+    return YAMD_OK;
+}
+
+extern "C" int yamd_depth_to_space2(const void *x, int x_cstride, void *y, int y_cstride, int batch, int h, int w, int c,
+                                    void *stream)
+{
+    YAMD_REQUIRE(x && y, "null argument");
+    YAMD_REQUIRE(batch > 0 && h > 0 && w > 0 && c > 0 && c % 8 == 0, "bad shape (c=%d must be a multiple of 8)", c);
+    YAMD_REQUIRE(x_cstride >= 4 * c && x_cstride % 8 == 0 && y_cstride % 8 == 0 && ((uintptr_t)x % 16) == 0 &&
+                     ((uintptr_t)y % 16) == 0, "depth_to_space needs 16-byte aligned pixels");
+    const long long total = (long long)batch * 4 * h * w * (c / 8);
+    hipLaunchKernelGGL(depth_to_space2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16 *)x, x_cstride, (__bf16 *)y, y_cstride, batch, h, w, c / 8);
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;

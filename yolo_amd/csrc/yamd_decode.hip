@@ -169,6 +169,57 @@ __global__ __launch_bounds__(256) void decode_dfl_kernel(DflParams p)
     for (int i = threadIdx.x; i < np * CO; i += 256) dst[i] = sout[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Anchor-free ltrb + landmark decode (no DFL): one workgroup per DPIX pixels of one level.
+struct LtrbParams {
+    const float *raw;
+    float *out;
+    int H, W, P, nc, stride, out_cxcywh;
+    long long rows_per_image, row_offset;
+};
+
+__global__ __launch_bounds__(256) void decode_ltrb_kernel(LtrbParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int HW = p.H * p.W;
+    const int CI = 4 + 2 * p.P + p.nc;     // input channels per pixel
+    const int CO = 5 + 2 * p.P + p.nc;     // output columns
+    float *sraw = sm;                      // DPIX * CI
+    float *sout = sm + DPIX * CI;          // DPIX * CO
+    const int p0 = blockIdx.x * DPIX;
+    const int np = min(DPIX, HW - p0);
+    const long long b = blockIdx.y;
+    const float *src = p.raw + (b * HW + p0) * (long long)CI;
+    for (int i = threadIdx.x; i < np * CI; i += 256) sraw[i] = src[i];
+    __syncthreads();
+    const float fs = (float)p.stride;
+    for (int i = threadIdx.x; i < np * CO; i += 256) {
+        const int pix = i / CO, c = i % CO, gp = p0 + pix;
+        // cell centre in grid units, computed like the reference: ((index + 0.5) * stride) / stride
+        const float ax = (((float)(gp % p.W) + 0.5f) * fs) / fs, ay = (((float)(gp / p.W) + 0.5f) * fs) / fs;
+        const float *r = sraw + pix * CI;
+        float v;
+        if (c < 4) {
+            const float x1 = (ax - r[0]) * fs, y1 = (ay - r[1]) * fs, x2 = (ax + r[2]) * fs, y2 = (ay + r[3]) * fs;
+            if (p.out_cxcywh)
+                v = c == 0 ? (x1 + x2) / 2.0f : (c == 1 ? (y1 + y2) / 2.0f : (c == 2 ? x2 - x1 : y2 - y1));
+            else
+                v = c == 0 ? x1 : (c == 1 ? y1 : (c == 2 ? x2 : y2));
+        } else if (c == 4) {
+            v = 1.0f;
+        } else if (c < 5 + 2 * p.P) {
+            const int k = c - 5;
+            v = (r[4 + k] + ((k & 1) ? ay : ax)) * fs;
+        } else {
+            v = 1.0f / (1.0f + expf(-r[c - 1]));
+        }
+        sout[i] = v;
+    }
+    __syncthreads();
+    float *dst = p.out + (b * p.rows_per_image + p.row_offset + p0) * (long long)CO;
+    for (int i = threadIdx.x; i < np * CO; i += 256) dst[i] = sout[i];
+}
+
 }  // namespace
 
 extern "C" int yamd_decode_anchor(int kind, const float *raw, int batch, int h, int w, int na, int c,
@@ -238,6 +289,38 @@ extern "C" int yamd_decode_dfl(const float *const *raw_host_ptrs, const int *hs,
         p.rows_per_image = rows;
         p.row_offset = off;
         hipLaunchKernelGGL(decode_dfl_kernel, dim3(ceil_div((long long)hs[i] * ws[i], DPIX), batch), dim3(256), lds,
+                           (hipStream_t)stream, p);
+        YAMD_LAUNCH_CHECK();
+        off += (long long)hs[i] * ws[i];
+    }
+    return YAMD_OK;
+}
+
+extern "C" int yamd_decode_ltrb_points(const float *const *raw_host_ptrs, const int *hs, const int *ws, const int *strides,
+                                       int n_levels, int batch, int point_num, int nc, int out_cxcywh, float *out,
+                                       void *stream)
+{
+    YAMD_REQUIRE(raw_host_ptrs && hs && ws && strides && out, "null argument");
+    YAMD_REQUIRE(n_levels > 0 && n_levels <= 8 && batch > 0 && batch <= 65535 && point_num >= 0 && nc > 0, "bad shape");
+    long long rows = 0;
+    for (int i = 0; i < n_levels; ++i) rows += (long long)hs[i] * ws[i];
+    const size_t lds = (size_t)DPIX * (4 + 2 * point_num + nc + 5 + 2 * point_num + nc) * sizeof(float);
+    YAMD_REQUIRE(lds <= 64 * 1024, "point_num/nc too large for the decode tile");
+    long long off = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        YAMD_REQUIRE(raw_host_ptrs[i] != nullptr && hs[i] > 0 && ws[i] > 0 && strides[i] > 0, "bad level %d", i);
+        LtrbParams p;
+        p.raw = raw_host_ptrs[i];
+        p.out = out;
+        p.H = hs[i];
+        p.W = ws[i];
+        p.P = point_num;
+        p.nc = nc;
+        p.stride = strides[i];
+        p.out_cxcywh = out_cxcywh ? 1 : 0;
+        p.rows_per_image = rows;
+        p.row_offset = off;
+        hipLaunchKernelGGL(decode_ltrb_kernel, dim3(ceil_div((long long)hs[i] * ws[i], DPIX), batch), dim3(256), lds,
                            (hipStream_t)stream, p);
         YAMD_LAUNCH_CHECK();
         off += (long long)hs[i] * ws[i];

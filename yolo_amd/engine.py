@@ -131,6 +131,21 @@ class Program:
         self.ops.append(("mp2", x, out))
         return out
 
+    def conv_transpose2x(self, name: str, x: View, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                         out: Optional[View] = None) -> View:
+        """nn.ConvTranspose2d(kernel 2, stride 2): weight (cin, cout, 2, 2).  Runs as a 1x1 conv to 4*cout channels
+        ordered (dy, dx, cout) followed by a depth-to-space scatter."""
+        cin, cout, kh, kw = weight.shape
+        assert (kh, kw) == (2, 2) and cin == x.c
+        w1 = weight.detach().permute(2, 3, 1, 0).reshape(4 * cout, cin, 1, 1)
+        b1 = None if bias is None else bias.detach().repeat(4)
+        t = self.conv(name, x, w1, b1, 1, _lib.ACT_NONE)
+        if out is None:
+            out = self.buffer(2 * x.h, 2 * x.w, cout)
+        assert (out.h, out.w, out.c) == (2 * x.h, 2 * x.w, cout)
+        self.ops.append(("d2s", t, out))
+        return out
+
     def cat(self, views: List[View], name: Optional[str] = None) -> View:
         """torch.cat(views, dim=1) without moving data where possible: a source that is a whole buffer of its
         own is re-homed into the concat buffer (its producers then write their channel slice in place, also
@@ -201,6 +216,8 @@ class Program:
             return 0.0, float(batch * op[1].h * op[1].w * op[1].c * 2 * 2)
         if kind == "mp2":
             return 0.0, float(batch * op[1].h * op[1].w * op[1].c * 2 * 1.25)
+        if kind == "d2s":
+            return 0.0, float(batch * op[1].h * op[1].w * op[1].c * 2 * 2)
         return 0.0, 0.0
 
     # ---- execution -------------------------------------------------------------------------------
@@ -267,6 +284,11 @@ class Program:
                 xp, xcs = P(bufs, x)
                 yp, ycs = P(bufs, out)
                 _lib.check(LIB.yamd_copy_channels(xp, xcs, yp, ycs, B * x.h * x.w, x.c, st), "copy")
+            elif kind == "d2s":
+                _, x, out = op
+                xp, xcs = P(bufs, x)
+                yp, ycs = P(bufs, out)
+                _lib.check(LIB.yamd_depth_to_space2(xp, xcs, yp, ycs, B, x.h, x.w, out.c, st), "depth_to_space2")
             elif kind == "mp2":
                 _, x, out = op
                 xp, xcs = P(bufs, x)

@@ -18,8 +18,9 @@ import torch
 
 def seeded_state_dict(model: torch.nn.Module, seed: int = 0, mode: str = "spread", scale: Dict[str, float] = None
                       ) -> "OrderedDict[str, torch.Tensor]":
-    """``scale`` maps a key suffix to a factor applied to the generated tensor (e.g. damping the last conv
-    of every residual branch so that a deep residual stack keeps its activation range)."""
+    """``scale`` maps a key fragment to a factor applied to the generated tensor of every key containing it
+    (e.g. damping the last conv of every residual branch so that a deep residual stack keeps its activation
+    range)."""
     rng = np.random.RandomState(seed)
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     bn_prefixes = {n + "." for n, m in model.named_modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)}
@@ -56,8 +57,8 @@ def seeded_state_dict(model: torch.nn.Module, seed: int = 0, mode: str = "spread
                 v = rng.uniform(-bound, bound, shape)
         else:
             v = ref.detach().cpu().double().numpy()                # constants (e.g. DFL projection)
-        for suffix, factor in (scale or {}).items():
-            if name.endswith(suffix):
+        for fragment, factor in (scale or {}).items():
+            if fragment in name:
                 v = np.asarray(v) * factor
         out[name] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape).copy())
     return out

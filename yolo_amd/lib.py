@@ -19,7 +19,7 @@ DECODE_V5, DECODE_V3, DECODE_POSE, DECODE_FACE = 0, 1, 2, 3
 EXPORTS = [
     "yamd_last_error", "yamd_version", "yamd_conv_desc_init", "yamd_conv_pack_weights", "yamd_conv2d_bias_act",
     "yamd_focus_pack", "yamd_nchw_to_nhwc16", "yamd_upsample2x", "yamd_maxpool2", "yamd_maxpool5_cascade",
-    "yamd_copy_channels",
+    "yamd_copy_channels", "yamd_depth_to_space2", "yamd_decode_ltrb_points",
     "yamd_decode_anchor", "yamd_decode_dfl", "yamd_nms_workspace_bytes", "yamd_nms_batched", "yamd_compact_rows",
 ]
 
@@ -56,6 +56,7 @@ def _load() -> ctypes.CDLL:
     lib.yamd_nchw_to_nhwc16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.yamd_upsample2x.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.yamd_maxpool2.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
+    lib.yamd_depth_to_space2.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.yamd_maxpool5_cascade.argtypes = [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                           c_int, c_void_p]
     lib.yamd_copy_channels.argtypes = [c_void_p, c_int, c_void_p, c_int, c_longlong, c_int, c_void_p]
@@ -63,6 +64,8 @@ def _load() -> ctypes.CDLL:
                                        c_float, c_int, c_int, c_void_p, c_longlong, c_longlong, c_void_p]
     lib.yamd_decode_dfl.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p, c_void_p]
+    lib.yamd_decode_ltrb_points.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                            c_void_p, c_void_p]
     lib.yamd_nms_workspace_bytes.restype = c_size_t
     lib.yamd_nms_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.yamd_nms_batched.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_double, c_void_p,

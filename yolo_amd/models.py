@@ -9,6 +9,7 @@ def registry() -> Dict[str, Dict[str, Any]]:
     from .yolov3 import YoloV3
     from .yolov4 import YoloV4
     from .yolov5 import YoloV5
+    from .yolov6_face import YoloV6Face
     from .yolov7_pose import YoloV7Pose
     from .yolov8 import YoloV8
     return {
@@ -22,6 +23,12 @@ def registry() -> Dict[str, Dict[str, Any]]:
                    init=dict(scale={".block.1.conv.weight": 0.25, "yolo_head1.1.weight": 0.05,
                                     "yolo_head2.1.weight": 0.05, "yolo_head3.1.weight": 0.05})),
         "v7pose": dict(cls=YoloV7Pose, param=lambda: _param.Yolo7PoseParam(m_type="l"), init={}),
+        # RepVGG blocks sum three un-normalised branches ~40 times in a row: scale the branch BatchNorms so that the
+        # sum keeps the activation variance; box/landmark logits (grid units, multiplied by the stride) get a std near 1
+        "v6face": dict(cls=YoloV6Face, param=lambda: _param.Yolo6FaceParam(m_type="s"),
+                       init=dict(scale={".rbr_dense.bn.weight": 0.55, ".rbr_1x1.bn.weight": 0.55,
+                                        ".rbr_identity.weight": 0.55, "reg_predict_list": 0.3,
+                                        "reg_point_predict_list": 0.3})),
     }
 
 

@@ -150,6 +150,24 @@ def decode_dfl(raws: List[torch.Tensor], strides, reg_max: int, nc: int, out_fmt
     return out
 
 
+def decode_ltrb_points(raws: List[torch.Tensor], strides, point_num: int, nc: int, out_fmt: str) -> torch.Tensor:
+    """raws[i]: (B,h,w,4+2P+nc) float32 NHWC [ltrb | landmarks | cls].  Returns (B, A, 5+2P+nc):
+    [box, 1.0, landmarks, scores] (luoyang/yolov6_face/YoloV6Face.py:42-58 and :66-74)."""
+    B = raws[0].shape[0]
+    n = len(raws)
+    for r in raws:
+        _lib.require_gpu(r, torch.float32, "raw head")
+    A = sum(r.shape[1] * r.shape[2] for r in raws)
+    out = torch.empty((B, A, 5 + 2 * point_num + nc), dtype=torch.float32, device=raws[0].device)
+    ptrs = (ctypes.c_void_p * n)(*[r.data_ptr() for r in raws])
+    hs = (ctypes.c_int * n)(*[r.shape[1] for r in raws])
+    ws = (ctypes.c_int * n)(*[r.shape[2] for r in raws])
+    ss = (ctypes.c_int * n)(*[int(s) for s in strides])
+    _lib.check(LIB.yamd_decode_ltrb_points(ptrs, hs, ws, ss, n, B, point_num, nc, 1 if out_fmt == "cxcywh" else 0,
+                                           out.data_ptr(), _lib.current_stream()), "decode_ltrb_points")
+    return out
+
+
 def fold_conv_bn(conv_w: torch.Tensor, conv_b: Optional[torch.Tensor], bn: nn.BatchNorm2d
                  ) -> Tuple[torch.Tensor, torch.Tensor]:
     """W' = diag(g/sqrt(var+eps)) W ; b' = beta - g*mean/sqrt(var+eps) + diag(..) b  (eval-mode BN)."""
