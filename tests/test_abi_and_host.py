@@ -115,3 +115,26 @@ def test_product_has_no_cpu_path():
     from yolo_amd import torch_utils as tu
     with pytest.raises(L.YamdError):
         tu.non_max_suppression(torch.zeros(1, 4, 25), 64)
+
+
+def test_checkpoint_architecture_detection(tmp_path):
+    """A state_dict saved the way the reference saves checkpoints (torch.save of net.state_dict()) is enough to
+    rebuild the right model, fused or not; loading uses weights_only=True."""
+    import torch
+    from yolo_amd import models
+    from yolo_amd.init import seeded_state_dict
+    for name in ("v5s", "v8s", "v4", "v7pose", "v6face"):
+        size = 128 if name == "v6face" else 64
+        p, m = models.create(name, size)
+        sd = seeded_state_dict(m, seed=2, mode="spread", **models.init_options(name))
+        path = tmp_path / f"{name}.pth"
+        torch.save(sd, path)
+        p2, m2 = models.from_state_dict(torch.load(path, map_location="cpu", weights_only=True), size)
+        assert type(m2) is type(m) and p2.class_num == p.class_num and p2.img_size == size
+        assert getattr(p2, "m_type", None) == getattr(p, "m_type", None)
+        assert list(m2.state_dict().keys()) == list(sd.keys())
+        if name in ("v4", "v7pose", "v6face"):
+            m.load_state_dict(sd)
+            m.fuse()
+            p3, m3 = models.from_state_dict(m.state_dict(), size)
+            assert list(m3.state_dict().keys()) == list(m.state_dict().keys())

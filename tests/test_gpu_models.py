@@ -130,3 +130,30 @@ def test_fused_equals_unfused(name, gpu_device):
     assert len(m.state_dict()) < n_before
     b = m._forward(imgs)[0].cpu().numpy()
     np.testing.assert_allclose(a, b, rtol=2e-3, atol=2e-3)
+
+
+def test_yolo_predict_entry_points(gpu_device, tmp_path):
+    """YoloPredict / YoloPosePredict built from a checkpoint file: same rows as non_max_suppression*(_forward(x)) and
+    as the TaskLayer route (predict) on the same weights, bit for bit."""
+    from yolo_amd import predict as PR, torch_utils as tu
+    from yolo_amd.init import seeded_images
+    p, m, sd = _model("v5s", 64, 11)
+    path = tmp_path / "v5s.pth"
+    torch.save(sd, path)
+    imgs = seeded_images(2, 64, seed=11)
+    yp = PR.YoloPredict(str(path), "cuda", (64, 64), 25, conf_threshold=p.conf_threshold, nms_threshold=p.nms_threshold)
+    got = yp.predict({"images": imgs})
+    head = yp.sess_predict({"images": imgs})
+    assert head.shape == (2, 252, 25) and head.dtype == np.float32
+    want = m.predict({"batch_images": torch.from_numpy(imgs).to(gpu_device)})["predicts"]
+    ref_rows = tu.non_max_suppression(torch.from_numpy(head).to(gpu_device), 64, "cxcywh", p.conf_threshold, p.nms_threshold)
+    for a, b, c in zip(got, want, ref_rows):
+        assert np.array_equal(a, b) and np.array_equal(a, c.cpu().numpy())
+    # pose flavour from a ready model object
+    p7, m7, _ = _model("v7pose", 64, 31)
+    pp = PR.YoloPosePredict(None, "cuda", 17, (64, 64), 57, conf_threshold=0.3, nms_threshold=0.3, model=m7)
+    got = pp.predict({"images": seeded_images(2, 64, seed=31)})
+    pred = m7._forward(torch.from_numpy(seeded_images(2, 64, seed=31)).to(gpu_device))[0]
+    want = tu.non_max_suppression_with_point_conf(pred, 64, 17, "cxcywh", 0.3, 0.3)
+    for a, b in zip(got, want):
+        assert (a is None and b is None) or np.array_equal(a, b.cpu().numpy())

@@ -43,3 +43,76 @@ def create(name: str, img_size: int = 0):
     if img_size:
         p.set_img_size(img_size)
     return p, e["cls"](p)
+
+
+def from_state_dict(sd, img_size: int, output_size: int = 0, point_num: int = 0):
+    """Builds the model a checkpoint belongs to from its key names and tensor shapes (what an ONNX export carries
+    implicitly) and loads it.  ``output_size`` is the per-anchor column count of ``_forward`` (5 + classes [+ points]);
+    0 derives the class count from the head convolutions."""
+    from .yolov3 import YoloV3
+    from .yolov4 import YoloV4
+    from .yolov5 import YoloV5
+    from .yolov6_face import YoloV6Face
+    from .yolov7_pose import YoloV7Pose
+    from .yolov8 import YoloV8
+    keys = sd.keys()
+
+    def has(k):
+        return k in keys
+
+    def width_type(w, table):
+        for t, v in table.items():
+            if v == w:
+                return t
+        raise ValueError(f"unrecognised network width {w}")
+
+    def with_classes(p, nc):
+        if nc != p.class_num:
+            p.class_names = [str(i) for i in range(nc)]
+            p.class_num = nc
+        return p
+
+    if has("body_net.darknet53.conv1.0.weight"):
+        nc = sd["body_net.last_layer0.6.weight"].shape[0] // 3 - 5
+        p, cls = with_classes(_param.Yolo3Param(), nc), YoloV3
+    elif has("body_net.backbone.stages.0.downsample_conv.conv.weight"):
+        nc = sd["body_net.yolo_head3.1.weight"].shape[0] // 3 - 5
+        p, cls = with_classes(_param.Yolo4Param(), nc), YoloV4
+    elif has("body_net.backbone.stem.conv.conv.weight"):
+        t = width_type(sd["body_net.backbone.stem.conv.conv.weight"].shape[0], {"s": 32, "m": 48, "l": 64, "x": 80})
+        nc = sd["body_net.yolo_head_P3.weight"].shape[0] // 3 - 5
+        p, cls = with_classes(_param.Yolo5Param(m_type=t), nc), YoloV5
+    elif has("head.proj") and has("body_net.backbone.stem.conv.weight"):
+        w0 = sd["body_net.backbone.stem.conv.weight"].shape[0]
+        n_bottle = sum(1 for k in keys if k.startswith("body_net.backbone.dark2.1.m.") and k.endswith("cv1.conv.weight"))
+        t = {(16, 1): "n", (32, 1): "s", (48, 2): "m", (64, 3): "l", (80, 3): "x"}[(w0, n_bottle)]
+        nc = sd["body_net.cv3.0.2.weight"].shape[0]
+        p, cls = with_classes(_param.Yolo8Param(m_type=t), nc), YoloV8
+    elif has("body_net.backbone.stem.0.conv.weight") or has("body_net.backbone.stem.0.conv.bias"):
+        t = width_type(sd["body_net.backbone.stem.0.conv.weight"].shape[0], {"l": 32, "x": 40})
+        p = _param.Yolo7PoseParam(m_type=t)
+        if point_num:
+            p.point_num = point_num
+        nc = sd["body_net.yolo_head_P3.weight"].shape[0] // 3 - 5 - 3 * p.point_num
+        p, cls = with_classes(p, nc), YoloV7Pose
+    elif any(k.startswith("yolo_body.back_bone_network.stem.") for k in keys):
+        k = "yolo_body.head.stems.0.block.conv.weight"
+        t = width_type(sd[k].shape[0], {"n": 32, "s": 64})
+        p = _param.Yolo6FaceParam(m_type=t)
+        p.num_layers = sum(1 for q in keys if q.startswith("yolo_body.head.stems.") and q.endswith("conv.weight"))
+        p.strides = [8, 16, 32, 64][:p.num_layers]
+        p, cls = with_classes(p, sd["yolo_body.head.cls_predict_list.0.weight"].shape[0]), YoloV6Face
+    else:
+        raise ValueError("checkpoint does not belong to a model family built on the HIP path")
+    p.set_img_size(img_size)
+    m = cls(p)
+    if set(keys) != set(m.state_dict().keys()):
+        try:
+            m.fuse()                  # a checkpoint saved after the reference's fuse() has that layout
+        except NotImplementedError:
+            pass
+    m.load_state_dict(sd, strict=True)
+    width = m._forward_width() if hasattr(m, "_forward_width") else 0
+    if output_size and width and width != output_size:
+        raise ValueError(f"checkpoint decodes to {width} columns per anchor, caller expects {output_size}")
+    return p, m
