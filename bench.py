@@ -37,7 +37,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE config: 256)")
+    ap.add_argument("--model", default="v5s", help="model family (yolo_amd.models.registry); v5s is the headline config")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the BASELINE config of the model)")
     ap.add_argument("--weights", default="torch_default", choices=["torch_default", "spread"],
                     help="seeded random-init scheme (torch_default = the reference's YoloV5(param) distribution)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -81,13 +82,18 @@ def max_over_ranks(value: float, world: int, dry: bool) -> float:
     return float(t.item())
 
 
-def build_model(weights: str):
+# per-GPU batch of the BASELINE configurations (v8s: 1024 images over 8 GPUs)
+DEFAULT_BATCH = {"v5s": 256, "v8s": 128, "v7pose": 512, "v6face": 512, "v3": 256, "v4": 256}
+LABEL = {"v5s": "YOLOv5s VOC-20 detect", "v8s": "YOLOv8s VOC-20 detect", "v7pose": "YOLOv7-l pose (17 keypoints)",
+         "v6face": "YOLOv6-s face (5 landmarks, 4 levels)", "v3": "YOLOv3 VOC-20 detect", "v4": "YOLOv4 VOC-20 detect"}
+
+
+def build_model(name: str, weights: str):
+    from yolo_amd import models
     from yolo_amd.init import seeded_state_dict
-    from yolo_amd.param import Yolo5Param
-    from yolo_amd.yolov5 import YoloV5
-    p = Yolo5Param(m_type="s").set_img_size(IMG)
-    m = YoloV5(p)
-    sd = seeded_state_dict(m, seed=0, mode=weights)
+    p, m = models.create(name)
+    opts = models.init_options(name) if weights == "spread" else {}
+    sd = seeded_state_dict(m, seed=0, mode=weights, **opts)
     m.load_state_dict(sd)
     return p, m, sd
 
@@ -191,39 +197,40 @@ def stage_profile(model, p, images, reps=3):
     dec_ms = nms_ms = 0.0
     for _ in range(reps):
         ev[0].record()
-        pred = tu.decode_anchor_levels(raws, p.anchors, p.strides, p.img_size, L.DECODE_V5)
+        pred = model.decode_predict(raws)
         ev[1].record()
-        rows, counts, _ = tu.nms_batched(pred, p.img_size, "cxcywh", p.conf_threshold, p.nms_threshold)
+        rows, counts = model.nms_predict(pred)
         ev[2].record()
         torch.cuda.synchronize()
         dec_ms += ev[0].elapsed_time(ev[1]) / reps
         nms_ms += ev[1].elapsed_time(ev[2]) / reps
-    A, C = pred.shape[1], pred.shape[2]
-    dec_bytes = B * A * C * 8.0
+    dec_bytes = float(sum(r.numel() for r in raws) + pred.numel()) * 4.0      # raw logits read + decoded rows written
     return dict(table=table, conv_ms=conv_ms, conv_flops=conv_fl, n_conv=n_conv, decode_ms=dec_ms, decode_bytes=dec_bytes,
                 nms_ms=nms_ms, other_ms=sum(r["ms"] for r in table if r["kind"] != "conv"))
 
 
-def cpu_baseline(sd, p, n_images):
+def cpu_baseline(name, sd, p, n_images):
     """The CPU oracle (torch fp32 graph + numpy decode + C NMS) timed on the host cores: reported baseline."""
-    from oracle import decode_ref, postprocess, v5_ref
+    from oracle import graphs_ref, postprocess
     from yolo_amd.init import seeded_images
     threads = max(1, min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
     torch.set_num_threads(threads)
-    imgs = torch.from_numpy(seeded_images(n_images, IMG, seed=0))
+    imgs = torch.from_numpy(seeded_images(n_images, p.img_size, seed=0))
+    ref = graphs_ref.model_ref(name)
 
     def once(x):
         with torch.no_grad():
-            raws = [t.numpy() for t in v5_ref.body_forward(sd, x)]
-        pred = decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "v5")
-        return postprocess.non_max_suppression(pred, p.img_size, "cxcywh", p.conf_threshold, p.nms_threshold)
+            raws = [t.numpy() for t in ref["body"](sd, x)]
+        pred = ref["decode"](raws, p, True)
+        return postprocess.non_max_suppression(pred, p.img_size, conf_threshold=p.conf_threshold,
+                                               nms_threshold=p.nms_threshold, **ref["nms"])
 
     once(imgs[:1])
     t0 = time.perf_counter()
     once(imgs)
     dt = time.perf_counter() - t0
     return dict(value=round(n_images / dt, 3), unit="images/s", cores=threads, kind="port",
-                sample=f"{n_images} images 640x640 in one batch, 1 timed pass after a 1-image warm-up; torch-CPU fp32 conv "
+                sample=f"{n_images} images {p.img_size}x{p.img_size} in one batch, 1 timed pass after a 1-image warm-up; torch-CPU fp32 conv "
                        f"graph + numpy decode + C NMS of oracle/ ({dt:.2f} s)")
 
 
@@ -244,13 +251,15 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     from yolo_amd.init import seeded_images
-    p, model, sd = build_model(args.weights)
-    B = args.batch
+    p, model, sd = build_model(args.model, args.weights)
+    B = args.batch or DEFAULT_BATCH[args.model]
+    IMG = p.img_size
     # synthetic uniform[0,1) images, seeded per global image index; resident in HBM before timing starts
     base = seeded_images(min(B, 32), IMG, seed=0, start=rank * B)
     images = torch.from_numpy(base).to(dev).repeat((B + base.shape[0] - 1) // base.shape[0], 1, 1, 1)[:B].contiguous()
-    A = sum(3 * (IMG // s) ** 2 for s in p.strides)
-    sink = HostSink(B, A, 7, dev)
+    rows0, _ = model.predict_device(images[:1])
+    A, width = rows0.shape[1], rows0.shape[2]
+    sink = HostSink(B, A, width, dev)
 
     for _ in range(args.warmup):
         step(model, images, sink)
@@ -270,15 +279,16 @@ def main():
         prof = stage_profile(model, p, images)
         conv_tflops = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
         # candidates per image (score >= conf) on the first images, for the record
-        pred = model._forward(images[:8])[0]
-        cand = ((pred[..., 4] * pred[..., 5:].max(-1).values) >= p.conf_threshold).sum(1).float().mean().item()
+        pred = model.decode_predict(model.raw_heads(images[:8]))
+        ncls = p.class_num
+        cand = ((pred[..., 4] * pred[..., -ncls:].max(-1).values) >= p.conf_threshold).sum(1).float().mean().item()
         out = {
             "metric": METRIC, "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "YOLOv5s VOC-20 detect, 640x640, batch %d per GPU, conv graph bf16 (fp32 accumulate) + "
+            "config": {"workload": "%s, %dx%d, batch %d per GPU, conv graph bf16 (fp32 accumulate) + "
                                    "fp32 decode + per-class NMS + D2H of kept rows; random-init weights (%s, seed 0)"
-                                   % (B, args.weights),
+                                   % (LABEL[args.model], IMG, IMG, B, args.weights),
                        "batch_per_gpu": B, "parallelism": "batch-sharded x%d, no collective" % world,
                        "conf_threshold": p.conf_threshold, "nms_threshold": p.nms_threshold,
                        "candidates_per_image": round(cand, 1), "kept_per_image": round(float(counts.mean()), 1),
@@ -295,7 +305,7 @@ def main():
                            "frac": round(prof["decode_bytes"] / (prof["decode_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(sd, p, args.cpu_images)
+            out["cpu_baseline"] = cpu_baseline(args.model, sd, p, args.cpu_images)
         if args.detail:
             with open(args.detail, "w") as f:
                 for r in sorted(prof["table"], key=lambda r: -r["ms"]):

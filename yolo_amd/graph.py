@@ -93,6 +93,20 @@ class TaskModel(nn.Module):
                 delattr(m, bn_name)
         self.invalidate()
 
+    # the three stages of predict(): raw head logits -> decoded (B,A,C) tensor -> kept rows, all on the device
+    def raw_heads(self, images: torch.Tensor) -> List[torch.Tensor]:      # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def decode_predict(self, raws) -> torch.Tensor:                       # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def nms_predict(self, pred: torch.Tensor):                            # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def predict_device(self, images: torch.Tensor):
+        """Whole path on the device: returns (rows (B,A,W), counts (B,)) without synchronising."""
+        return self.nms_predict(self.decode_predict(self.raw_heads(images)))
+
     def fuse(self):
         """Models without a re-parameterisation step in the reference raise there too (model/Layer.py TaskLayer.fuse);
         BatchNorm is folded when the plan is compiled, so callers have nothing to do."""
@@ -146,9 +160,10 @@ class AnchorTaskModel(TaskModel):
     def _n_extra(self) -> int:
         return (3 if self.POINT_CONF else 2) * self.POINT_NUM
 
-    def predict_device(self, images: torch.Tensor):
-        """Whole path on the device: returns (rows (B,A,W), counts (B,)) without synchronising."""
-        pred = self._merge(self.raw_heads(images), self.POINT_NUM > 0 and self.POINT_CONF)
+    def decode_predict(self, raws) -> torch.Tensor:
+        return self._merge(raws, self.POINT_NUM > 0 and self.POINT_CONF)
+
+    def nms_predict(self, pred: torch.Tensor):
         rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "cxcywh", self.param.conf_threshold,
                                                   self.param.nms_threshold, self._n_extra())
         return rows, counts
@@ -156,8 +171,6 @@ class AnchorTaskModel(TaskModel):
     def predict(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:
         """Adds ``predicts``: per image ``None`` or ndarray (K, W) in the reference's row layout."""
         tensor_dict = self._feed_forward(tensor_dict)
-        pred = self._merge(tensor_dict.pop("_raw_heads"), self.POINT_NUM > 0 and self.POINT_CONF)
-        rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "cxcywh", self.param.conf_threshold,
-                                                  self.param.nms_threshold, self._n_extra())
+        rows, counts = self.nms_predict(self.decode_predict(tensor_dict.pop("_raw_heads")))
         tensor_dict["predicts"] = torch_utils.rows_to_host(rows, counts)     # one packed D2H for the batch
         return tensor_dict

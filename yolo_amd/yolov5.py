@@ -6,7 +6,7 @@ identical (``body_net.backbone.stem.conv.conv.weight`` ...) and reference checkp
 The modules below only hold parameters: the conv graph is compiled into a ``engine.Program`` of
 fused HIP kernels (BN folded, concat in place, bf16 NHWC), decode and NMS run in their own kernels.
 """
-from typing import Any, Dict, List, Optional, Union
+from typing import Optional
 
 import torch
 import torch.nn as nn
@@ -14,6 +14,7 @@ import torch.nn as nn
 from . import lib as _lib
 from . import torch_utils
 from .engine import Program, View
+from .graph import AnchorTaskModel
 from .param import Yolo5Param
 
 _DEPTH = {"s": 0.33, "m": 0.67, "l": 1.00, "x": 1.33}
@@ -98,9 +99,11 @@ class _Builder:
         return self.cbs(f"{name}.cv3", m.cv3, cat, out=out)
 
 
-class YoloV5(nn.Module):
+class YoloV5(AnchorTaskModel):
     """``YoloV5(param)`` as in the reference; inputs/outputs of ``forward``/``predict`` are the
     reference's ``tensor_dict`` entries.  Images must be CUDA float32 NCHW in [0,1]."""
+
+    DECODE_KIND = _lib.DECODE_V5
 
     def __init__(self, param: Yolo5Param, anchor_num: int = 3):
         super().__init__()
@@ -109,29 +112,9 @@ class YoloV5(nn.Module):
         self.body_output_size = 5 + param.class_num
         t = param.m_type.split("_")[-1]
         self.body_net = _tree(param.class_num, anchor_num, _WIDTH[t], _DEPTH[t])
-        self._program: Optional[Program] = None
-        self._program_key = None
         self.eval()
 
-    # ---- plan --------------------------------------------------------------------------------
-    def invalidate(self) -> None:
-        """Drop the compiled plan (call after changing weights in place)."""
-        self._program = None
-
-    def load_state_dict(self, *a, **k):
-        self.invalidate()
-        return super().load_state_dict(*a, **k)
-
-    def program(self) -> Program:
-        key = (self.param.img_size,)
-        if self._program is None or self._program_key != key:
-            self._program = self._compile(self.param.img_size)
-            self._program_key = key
-        return self._program
-
     def _compile(self, S: int) -> Program:
-        if S % 32:
-            raise _lib.YamdError("img_size must be a multiple of 32")
         body, bb = self.body_net, self.body_net.backbone
         P = Program(S, S)
         B = _Builder(P)
@@ -176,59 +159,7 @@ class YoloV5(nn.Module):
                                      _lib.ACT_NONE, out_f32=True)
         return P
 
-    # ---- reference interface -------------------------------------------------------------------
-    def raw_heads(self, images: torch.Tensor) -> List[torch.Tensor]:
-        """Raw head logits [P3, P4, P5], float32 NHWC (B,h,w,3*(5+nc))."""
-        out = self.program().run(images)
-        return [out["P3"], out["P4"], out["P5"]]
-
-    def _anchors(self, level: int):
-        na = self.anchor_num
-        return self.param.anchors[level * na:(level + 1) * na]
-
-    def _forward(self, images: torch.Tensor) -> List[torch.Tensor]:
-        """[(B, A, 5+nc)] merged, cxcywh in input pixels (YoloV5.py:48-71)."""
-        raws = self.raw_heads(images)
-        return [torch_utils.decode_anchor_levels(raws, self.param.anchors, self.param.strides, self.param.img_size,
-                                                 _lib.DECODE_V5)]
-
-    def _feed_forward(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:
-        raws = self.raw_heads(tensor_dict["batch_images"])
-        for i, name in enumerate(("head3_predicts", "head4_predicts", "head5_predicts")):
-            tensor_dict[name] = torch_utils.decode_anchor_head(raws[i], self._anchors(i), self.param.strides[i],
-                                                               _lib.DECODE_V5)
-        tensor_dict["_raw_heads"] = raws
-        return tensor_dict
-
-    def forward(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:
-        return self._feed_forward(tensor_dict)
-
-    def predict_device(self, images: torch.Tensor):
-        """Whole path on the device: returns (rows (B,A,7), counts (B,)) without synchronising."""
-        pred = self._forward(images)[0]
-        rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "cxcywh", self.param.conf_threshold,
-                                                  self.param.nms_threshold)
-        return rows, counts
-
-    def predict(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:
-        """Adds ``predicts``: per image ``None`` or ndarray (K,7) [x1,y1,x2,y2,obj,cls_conf,cls_id]."""
-        tensor_dict = self._feed_forward(tensor_dict)
-        raws = tensor_dict.pop("_raw_heads")
-        pred = torch_utils.decode_anchor_levels(raws, self.param.anchors, self.param.strides, self.param.img_size,
-                                                _lib.DECODE_V5)
-        rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "cxcywh", self.param.conf_threshold,
-                                                  self.param.nms_threshold)
-        tensor_dict["predicts"] = torch_utils.rows_to_host(rows, counts)     # one packed D2H for the batch
-        return tensor_dict
-
     def fuse(self) -> None:
         """Fold every BatchNorm into its conv (YoloV5.py:171-176); ``state_dict`` then matches a fused
         reference model (conv.weight + conv.bias, no bn.*)."""
-        for m in self.modules():
-            if hasattr(m, "bn") and isinstance(getattr(m, "conv", None), nn.Conv2d):
-                m.conv = torch_utils.fuse_conv_and_bn(m.conv, m.bn)
-                delattr(m, "bn")
-        self.invalidate()
-
-    def to_onnx(self, onnx_path: str):
-        raise NotImplementedError("ONNX export is outside the accelerated path; use the reference for export")
+        self.fuse_conv_bn_holders()

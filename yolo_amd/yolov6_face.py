@@ -261,17 +261,17 @@ class YoloV6Face(TaskModel):
         tensor_dict["_pred_xyxy"] = pred
         return tensor_dict
 
-    def predict_device(self, images: torch.Tensor):
-        pred = self._decode(self.raw_heads(images), "xyxy")
+    def decode_predict(self, raws) -> torch.Tensor:
+        return self._decode(raws, "xyxy")
+
+    def nms_predict(self, pred: torch.Tensor):
         rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "xyxy", self.param.conf_threshold,
                                                   self.param.nms_threshold, 2 * self.param.point_num)
         return rows, counts
 
     def predict(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:
         tensor_dict = self.forward(tensor_dict)
-        pred = tensor_dict.pop("_pred_xyxy")
-        rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "xyxy", self.param.conf_threshold,
-                                                  self.param.nms_threshold, 2 * self.param.point_num)
+        rows, counts = self.nms_predict(tensor_dict.pop("_pred_xyxy"))
         tensor_dict["predicts"] = torch_utils.rows_to_host(rows, counts)
         return tensor_dict
 

@@ -173,8 +173,10 @@ class YoloV8(TaskModel):
         tensor_dict.pop("_raw_heads")
         return tensor_dict
 
-    def predict_device(self, images: torch.Tensor):
-        pred = self._decode(self.raw_heads(images), "xyxy")
+    def decode_predict(self, raws) -> torch.Tensor:
+        return self._decode(raws, "xyxy")
+
+    def nms_predict(self, pred: torch.Tensor):
         rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "xyxy", self.param.conf_threshold,
                                                   self.param.nms_threshold)
         return rows, counts
@@ -182,8 +184,6 @@ class YoloV8(TaskModel):
     def predict(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:
         """Adds ``predicts``: per image ``None`` or ndarray (K,7) [x1,y1,x2,y2,conf,cls_conf,cls_id]."""
         tensor_dict = self._feed_forward(tensor_dict)
-        pred = self._decode(tensor_dict.pop("_raw_heads"), "xyxy")
-        rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "xyxy", self.param.conf_threshold,
-                                                  self.param.nms_threshold)
+        rows, counts = self.nms_predict(self.decode_predict(tensor_dict.pop("_raw_heads")))
         tensor_dict["predicts"] = torch_utils.rows_to_host(rows, counts)
         return tensor_dict
