@@ -39,6 +39,7 @@ struct ConvParams {
     int H, W, Hout, Wout, Cout;
     int TH, tiles_x, tiles_y, n_tiles, nchunks;
     int act;
+    int total_tiles;
 };
 
 // Activations on the fp32 accumulator with hardware exp/rcp (about 1 ulp each); the result is rounded to
@@ -97,7 +98,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
     char *ldsW = smem;
     char *ldsA = smem + WBYTES;
 
-    int bid = blockIdx.x;
+    // Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  Give every XCD a
+    // contiguous range of logical tiles instead, so the cout tiles of one pixel tile (same input) and spatially
+    // neighbouring tiles (shared halo) run on the same XCD at about the same time.
+    const int per_xcd = gridDim.x >> 3;
+    int bid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (bid >= p.total_tiles) return;
     const int nt = bid % p.n_tiles;
     bid /= p.n_tiles;
     const int tx = bid % p.tiles_x;
@@ -331,9 +337,12 @@ int launch_conv(const ConvParams &p, int batch, hipStream_t stream)
         attr_err = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     YAMD_HIP(attr_err);
-    const long long grid = (long long)batch * p.tiles_y * p.tiles_x * p.n_tiles;
-    YAMD_REQUIRE(grid > 0 && grid < (1ll << 31), "conv grid out of range");
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
+    const long long total = (long long)batch * p.tiles_y * p.tiles_x * p.n_tiles;
+    YAMD_REQUIRE(total > 0 && total < (1ll << 31) - 8, "conv grid out of range");
+    ConvParams q = p;
+    q.total_tiles = (int)total;
+    const long long grid = (total + 7) / 8 * 8;      // a multiple of the XCD count; surplus workgroups exit at once
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, q);
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
 }

@@ -87,16 +87,29 @@ class _Builder:
         return self.p.conv(name, x, w, b, conv.stride[0], _lib.ACT_SILU, out=out, residual=residual)
 
     def c3(self, name: str, m: nn.Module, x: View, shortcut: bool, out: Optional[View] = None) -> View:
+        """cv1 and cv2 read the same input, so they run as ONE conv with their output channels side by side:
+        buffer = [last bottleneck out | cv2 out | cv1 out]; cv3 reads the first two slices (the reference's
+        cat((m(cv1(x)), cv2(x)), 1)).  Saves one full read of x and one launch per C3."""
         h = m.cv1.conv.out_channels
-        cat = self.p.buffer(x.h, x.w, 2 * h)
         n = len(m.m)
-        a = self.cbs(f"{name}.cv1", m.cv1, x, out=cat.slice(0, h) if n == 0 else None)
+        assert n >= 1
+        buf = self.p.buffer(x.h, x.w, 3 * h)
+        w1, b1 = self._folded(m.cv1)
+        w2, b2 = self._folded(m.cv2)
+        self.p.conv(f"{name}.cv2+cv1", x, torch.cat((w2, w1), 0), torch.cat((b2, b1), 0), 1, _lib.ACT_SILU,
+                    out=buf.slice(h, 2 * h))
+        a = buf.slice(2 * h, h)
         for i, bot in enumerate(m.m):
             t = self.cbs(f"{name}.m.{i}.cv1", bot.cv1, a)
-            a = self.cbs(f"{name}.m.{i}.cv2", bot.cv2, t, out=cat.slice(0, h) if i == n - 1 else None,
+            a = self.cbs(f"{name}.m.{i}.cv2", bot.cv2, t, out=buf.slice(0, h) if i == n - 1 else None,
                          residual=a if shortcut else None)
-        self.cbs(f"{name}.cv2", m.cv2, x, out=cat.slice(h, h))
-        return self.cbs(f"{name}.cv3", m.cv3, cat, out=out)
+        return self.cbs(f"{name}.cv3", m.cv3, buf.slice(0, 2 * h), out=out)
+
+    @staticmethod
+    def _folded(m: nn.Module):
+        if hasattr(m, "bn"):
+            return torch_utils.fold_conv_bn(m.conv.weight, m.conv.bias, m.bn)
+        return m.conv.weight.detach().float(), m.conv.bias.detach().float()
 
 
 class YoloV5(AnchorTaskModel):
