@@ -61,6 +61,12 @@ typedef struct yamd_conv_desc {
 
 int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int cin, int cout, int act, int out_f32);
 
+/* Optional: override the tiling chosen by yamd_conv_desc_init (per-layer tuning) before the weights are packed.
+ * mrep in {1,2}: 128 or 256 output pixels per workgroup; nrep in {1,2,4}: 32*nrep output channels per workgroup;
+ * ck in {16,32,64}: input channels staged per step.  Fails if that kernel is not built.  No counterpart in the
+ * reference (MIOpen picks its own algorithm there). */
+int yamd_conv_desc_tune(yamd_conv_desc *d, int mrep, int nrep, int ck);
+
 /* Host-side: fold nothing, just reorder.  w_oihw_host is float [cout][cin_real][k][k] (BN already
  * folded by the caller, cf. utils/torch_utils.py:344-370), bias_host float[cout] or NULL.
  * Writes packed bf16 weights (d->packed_w_elems uint16) and float bias (d->cout_pad). */

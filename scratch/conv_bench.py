@@ -1,6 +1,6 @@
 """Single-layer conv microbenchmark: python scratch/conv_bench.py k s cin cout H [B] [reps]"""
 import ctypes, sys, time, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from yolo_amd import lib as L
 k, s, cin, cout, H = [int(v) for v in sys.argv[1:6]]
 B = int(sys.argv[6]) if len(sys.argv) > 6 else 256

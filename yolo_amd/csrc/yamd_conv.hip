@@ -64,6 +64,27 @@ extern "C" int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int
     return YAMD_OK;
 }
 
+extern "C" int yamd_conv_desc_tune(yamd_conv_desc *d, int mrep, int nrep, int ck)
+{
+    YAMD_REQUIRE(d != nullptr, "null descriptor");
+    YAMD_REQUIRE((mrep == 1 || mrep == 2) && (nrep == 1 || nrep == 2 || nrep == 4) && (ck == 16 || ck == 32 || ck == 64),
+                 "bad tiling mrep=%d nrep=%d ck=%d", mrep, nrep, ck);
+    YAMD_REQUIRE(d->cin % ck == 0, "cin=%d is not a multiple of ck=%d", d->cin, ck);
+    YAMD_REQUIRE(!d->out_f32, "the float-output kernel has one tiling");
+    bool built;
+    if (d->ksize == 1) built = ck >= 32;
+    else if (d->stride == 1) built = (ck == 16 && (nrep == 1 || nrep == 4)) || (ck == 32 && (nrep == 1 || nrep == 2));
+    else built = mrep == 1 && ((ck == 16) || (ck == 32 && nrep == 2));
+    YAMD_REQUIRE(built, "no kernel built for k=%d s=%d mrep=%d nrep=%d ck=%d", d->ksize, d->stride, mrep, nrep, ck);
+    d->mrep = mrep;
+    d->nrep = nrep;
+    d->ck = ck;
+    const int bn = nrep * 32;
+    d->cout_pad = ((d->cout + bn - 1) / bn) * bn;
+    d->packed_w_elems = (int64_t)d->cout_pad * d->cin * d->ksize * d->ksize;
+    return YAMD_OK;
+}
+
 static inline uint16_t f32_to_bf16_rne(float f)
 {
     uint32_t u;

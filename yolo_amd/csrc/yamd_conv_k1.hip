@@ -4,16 +4,28 @@
 namespace yamd {
 int conv_dispatch_k1(const ConvParams &p, int batch, int tw, int mrep, int nrep, int ck, int f32, hipStream_t st)
 {
+    if (mrep == 1 && nrep == 1 && ck == 32 && f32 == 0)
+        return launch_conv_variant<1, 1, 1, 1, 32, false>(p, batch, tw, st);
+    if (mrep == 1 && nrep == 1 && ck == 64 && f32 == 0)
+        return launch_conv_variant<1, 1, 1, 1, 64, false>(p, batch, tw, st);
+    if (mrep == 1 && nrep == 2 && ck == 32 && f32 == 0)
+        return launch_conv_variant<1, 1, 1, 2, 32, false>(p, batch, tw, st);
+    if (mrep == 1 && nrep == 2 && ck == 64 && f32 == 0)
+        return launch_conv_variant<1, 1, 1, 2, 64, false>(p, batch, tw, st);
+    if (mrep == 1 && nrep == 4 && ck == 32 && f32 == 0)
+        return launch_conv_variant<1, 1, 1, 4, 32, false>(p, batch, tw, st);
+    if (mrep == 1 && nrep == 4 && ck == 64 && f32 == 0)
+        return launch_conv_variant<1, 1, 1, 4, 64, false>(p, batch, tw, st);
     if (mrep == 2 && nrep == 1 && ck == 32 && f32 == 0)
         return launch_conv_variant<1, 1, 2, 1, 32, false>(p, batch, tw, st);
-    if (mrep == 2 && nrep == 2 && ck == 32 && f32 == 0)
-        return launch_conv_variant<1, 1, 2, 2, 32, false>(p, batch, tw, st);
-    if (mrep == 2 && nrep == 4 && ck == 32 && f32 == 0)
-        return launch_conv_variant<1, 1, 2, 4, 32, false>(p, batch, tw, st);
     if (mrep == 2 && nrep == 1 && ck == 64 && f32 == 0)
         return launch_conv_variant<1, 1, 2, 1, 64, false>(p, batch, tw, st);
+    if (mrep == 2 && nrep == 2 && ck == 32 && f32 == 0)
+        return launch_conv_variant<1, 1, 2, 2, 32, false>(p, batch, tw, st);
     if (mrep == 2 && nrep == 2 && ck == 64 && f32 == 0)
         return launch_conv_variant<1, 1, 2, 2, 64, false>(p, batch, tw, st);
+    if (mrep == 2 && nrep == 4 && ck == 32 && f32 == 0)
+        return launch_conv_variant<1, 1, 2, 4, 32, false>(p, batch, tw, st);
     if (mrep == 2 && nrep == 4 && ck == 64 && f32 == 0)
         return launch_conv_variant<1, 1, 2, 4, 64, false>(p, batch, tw, st);
     if (mrep == 2 && nrep == 4 && ck == 64 && f32 == 1)

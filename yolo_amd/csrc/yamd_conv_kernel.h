@@ -40,7 +40,21 @@ struct ConvParams {
     int TH, tiles_x, tiles_y, n_tiles, nchunks;
     int act;
     int total_tiles;
+#ifdef YAMD_CONV_TRACE
+    unsigned long long *trace;   // 8 timestamps per workgroup (profiling builds only)
+#endif
 };
+
+#ifdef YAMD_CONV_TRACE
+#define YAMD_STAMP(i)                                                                              \
+    do {                                                                                           \
+        if (threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define YAMD_STAMP(i) \
+    do {              \
+    } while (0)
+#endif
 
 // Activations on the fp32 accumulator with hardware exp/rcp (about 1 ulp each); the result is rounded to
 // bf16 (8 significant bits) or feeds raw logits only for YAMD_ACT_NONE, so this loses nothing.
@@ -104,6 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
     const int per_xcd = gridDim.x >> 3;
     int bid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (bid >= p.total_tiles) return;
+    YAMD_STAMP(0);
     const int nt = bid % p.n_tiles;
     bid /= p.n_tiles;
     const int tx = bid % p.tiles_x;
@@ -125,19 +140,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
         if (pr >= p.TH) { pr = 0; pc = 0; }   // slot beyond the tile: read something valid, never stored
         pixoff[m] = ((pr * S) * NPW + pc) * RS + g * 16;
     }
-
-    // accumulators start at the bias: register 4i+j of fragment n is cout n*32 + 8i + 4g + j
-    f32x16 acc[MREP][NREP];
-#pragma unroll
-    for (int n = 0; n < NREP; ++n)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 bv = *(const f32x4 *)(p.bias + nt * (NREP * 32) + n * 32 + 8 * i + 4 * g);
-#pragma unroll
-            for (int m = 0; m < MREP; ++m)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[m][n][4 * i + j] = bv[j];
-        }
 
     // Staging registers: the next chunk's global loads are issued before the current chunk is computed
     // and written to LDS afterwards, so HBM/L2 latency hides under the MFMA work.
@@ -195,9 +197,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
         });
     };
 
+    YAMD_STAMP(1);
     issue_loads(0);
+    // (the first chunk is in flight while this runs) accumulators start at the bias: register 4i+j of fragment n is cout n*32 + 8i + 4g + j
+    f32x16 acc[MREP][NREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 bv = *(const f32x4 *)(p.bias + nt * (NREP * 32) + n * 32 + 8 * i + 4 * g);
+#pragma unroll
+            for (int m = 0; m < MREP; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[m][n][4 * i + j] = bv[j];
+        }
+
     write_lds();
     __syncthreads();
+    YAMD_STAMP(2);
     for (int ch = 0; ch < p.nchunks; ++ch) {
         const bool more = ch + 1 < p.nchunks;
         if (more) issue_loads(ch + 1);
@@ -227,6 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
         }
     }
 
+    YAMD_STAMP(3);
     // epilogue: lane holds, for pixel c32 of each fragment, couts 8*i + 4*g + j (i,j = 0..3)
     if constexpr (OUT_F32) {
 #pragma unroll
@@ -263,20 +281,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
             const int pr = pp / TW, pc = pp % TW;
             const bool valid = pr < p.TH && oh0 + pr < p.Hout && ow0 + pc < p.Wout;
             const size_t pix = (size_t)(b * p.Hout + oh0 + pr) * p.Wout + ow0 + pc;
+            // residual: all loads of this fragment are issued up front (clamped address instead of a divergent
+            // branch), so the epilogue pays one memory latency, not one per register quad
+            const bool has_res = p.res != nullptr;      // uniform
+            bf16x4 rr[NREP][4];
+            if (has_res) {
+#pragma unroll
+                for (int n = 0; n < NREP; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int co = nt * (NREP * 32) + n * 32 + 8 * i + 4 * g;
+                        const bool ok = valid && co < p.Cout;
+                        rr[n][i] = *(const bf16x4 *)(p.res + (ok ? pix * p.res_cs + co : (size_t)0));
+                    }
+            }
 #pragma unroll
             for (int n = 0; n < NREP; ++n) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int cl = n * 32 + 8 * i + 4 * g;
-                    const int co = nt * (NREP * 32) + cl;
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = acc[m][n][4 * i + j];
                     act4<ACT>(v);
-                    if (p.res && valid && co < p.Cout) {
-                        const bf16x4 r = *(const bf16x4 *)(p.res + pix * p.res_cs + co);
+                    if (has_res) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                        for (int j = 0; j < 4; ++j) v[j] += (float)rr[n][i][j];
                     }
                     bf16x4 o;
 #pragma unroll
@@ -318,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
             }
         }
     }
+    YAMD_STAMP(4);
 }
 
 template <int KS, int S, int TW, int MREP, int NREP, int CK, bool OUT_F32, int ACTK>

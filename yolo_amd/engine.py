@@ -32,25 +32,37 @@ class ConvLayer:
     """One fused conv: descriptor + packed weights (host copies kept so any device can be fed)."""
 
     def __init__(self, name: str, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, act: int,
-                 cin_stored: int, out_f32: bool):
+                 cin_stored: int, out_f32: bool, tiling: Optional[Tuple[int, int, int]] = None):
         w = weight.detach().to(torch.float32).cpu().contiguous()
         cout, cin_real, k, k2 = w.shape
         assert k == k2
         self.name = name
         self.cin_real = cin_real
         self.macs_per_pixel = cout * cin_real * k * k
+        self._w = w
+        self._b = None if bias is None else bias.detach().to(torch.float32).cpu().contiguous()
+        self._args = (k, stride, cin_stored, cout, act, int(out_f32))
+        self.pack(tiling)
+
+    def pack(self, tiling: Optional[Tuple[int, int, int]] = None) -> None:
+        """(Re)build the descriptor and the packed weights; ``tiling`` = (mrep, nrep, ck) overrides the default."""
+        name = self.name
         self.desc = _lib.ConvDesc()
-        _lib.check(LIB.yamd_conv_desc_init(ctypes.byref(self.desc), k, stride, cin_stored, cout, act, int(out_f32)),
-                   f"conv_desc_init[{name}]")
+        _lib.check(LIB.yamd_conv_desc_init(ctypes.byref(self.desc), *self._args), f"conv_desc_init[{name}]")
+        if tiling is not None:
+            _lib.check(LIB.yamd_conv_desc_tune(ctypes.byref(self.desc), *tiling), f"conv_desc_tune[{name}]")
         wp = torch.empty(self.desc.packed_w_elems, dtype=torch.int16)
         bp = torch.empty(self.desc.cout_pad, dtype=torch.float32)
-        b = None if bias is None else bias.detach().to(torch.float32).cpu().contiguous()
-        _lib.check(LIB.yamd_conv_pack_weights(ctypes.byref(self.desc), w.data_ptr(), cin_real,
-                                              None if b is None else b.data_ptr(), wp.data_ptr(), bp.data_ptr()),
-                   f"conv_pack_weights[{name}]")
+        _lib.check(LIB.yamd_conv_pack_weights(ctypes.byref(self.desc), self._w.data_ptr(), self.cin_real,
+                                              None if self._b is None else self._b.data_ptr(), wp.data_ptr(),
+                                              bp.data_ptr()), f"conv_pack_weights[{name}]")
         self.w_host, self.b_host = wp, bp
         self.w_dev: Optional[torch.Tensor] = None
         self.b_dev: Optional[torch.Tensor] = None
+
+    @property
+    def tiling(self) -> Tuple[int, int, int]:
+        return (self.desc.mrep, self.desc.nrep, self.desc.ck)
 
     def to(self, device) -> None:
         if self.w_dev is None or self.w_dev.device != torch.device(device):
@@ -92,10 +104,12 @@ class Program:
              out: Optional[View] = None, residual: Optional[View] = None, out_f32: bool = False) -> View:
         k = weight.shape[-1]
         cout = weight.shape[0]
-        layer = ConvLayer(name, weight, bias, stride, act, x.c, out_f32)
         pad = k // 2
         ho = (x.h + 2 * pad - k) // stride + 1
         wo = (x.w + 2 * pad - k) // stride + 1
+        from . import tuning
+        layer = ConvLayer(name, weight, bias, stride, act, x.c, out_f32,
+                          None if out_f32 else tuning.lookup(k, stride, x.c, cout, ho, wo))
         if out is None:
             out = self.buffer(ho, wo, cout, torch.float32 if out_f32 else torch.bfloat16)
         assert (out.h, out.w, out.c) == (ho, wo, cout), (name, out, ho, wo, cout)
@@ -178,6 +192,58 @@ class Program:
             buf, o = self.alias[buf]
             coff += o
         return buf, coff
+
+    # ---- per-layer tiling search ------------------------------------------------------------------
+    def autotune(self, batch: int, device, reps: int = 5, log=None) -> Dict[str, Tuple[int, int, int]]:
+        """Times every built tiling of every bf16 conv on this program's own buffers and keeps the fastest.
+        Returns {tuning key: (mrep, nrep, ck)} for ``tuning.save``."""
+        from . import tuning
+        bufs = self._buffers_for(batch, device)
+        st = _lib.current_stream()
+        best: Dict[str, Tuple[int, int, int]] = {}
+        for op in self.ops:
+            if op[0] != "conv" or op[1].desc.out_f32:
+                continue
+            _, layer, x, out, res = op
+            k, s = layer._args[0], layer._args[1]
+            key = tuning.key(k, s, x.c, out.c, out.h, out.w)
+            if key in best:
+                layer.pack(best[key])
+                layer.to(device)
+                continue
+            xp, xcs = self._ptr(bufs, x)
+            yp, ycs = self._ptr(bufs, out)
+            rp, rcs = self._ptr(bufs, res) if res is not None else (None, 0)
+            results = []
+            for cand in tuning.candidates(k, s, x.c, out.c):
+                try:
+                    layer.pack(cand)
+                except _lib.YamdError:
+                    continue
+                layer.to(device)
+
+                def run():
+                    _lib.check(LIB.yamd_conv2d_bias_act(ctypes.byref(layer.desc), xp, xcs, layer.w_dev.data_ptr(),
+                                                        layer.b_dev.data_ptr(), rp, rcs, yp, ycs, batch, x.h, x.w, st))
+                try:
+                    run()
+                except _lib.YamdError:
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(reps):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                results.append((e0.elapsed_time(e1) / reps, cand))
+            results.sort()
+            best[key] = results[0][1]
+            layer.pack(best[key])
+            layer.to(device)
+            if log is not None:
+                log(f"{layer.name:34s} {key:28s} " + "  ".join(f"{c}={t:.4f}" for t, c in results[:5]))
+        return best
 
     # ---- accounting ------------------------------------------------------------------------------
     def conv_macs_per_image(self) -> int:

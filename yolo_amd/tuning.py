@@ -1,0 +1,78 @@
+"""Per-layer conv tilings measured on the device (``Program.autotune``) and kept in a JSON table next to this
+file.  A layer without an entry uses the default rule of ``yamd_conv_desc_init``.
+
+  python -m yolo_amd.tuning --model v5s [--batch 256] [--out yolo_amd/tuned_gfx950.json]
+"""
+import json
+import os
+from typing import Dict, List, Optional, Tuple
+
+PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
+_table: Optional[Dict[str, List[int]]] = None
+enabled = os.environ.get("YAMD_NO_TUNING", "") == ""
+
+
+def key(k: int, s: int, cin: int, cout: int, ho: int, wo: int) -> str:
+    return f"k{k}s{s}_{cin}>{cout}@{ho}x{wo}"
+
+
+def table() -> Dict[str, List[int]]:
+    global _table
+    if _table is None:
+        _table = {}
+        if os.path.exists(PATH):
+            with open(PATH) as f:
+                _table = json.load(f)
+    return _table
+
+
+def lookup(k: int, s: int, cin: int, cout: int, ho: int, wo: int) -> Optional[Tuple[int, int, int]]:
+    if not enabled:
+        return None
+    t = table().get(key(k, s, cin, cout, ho, wo))
+    return None if t is None else (int(t[0]), int(t[1]), int(t[2]))
+
+
+def candidates(k: int, s: int, cin: int, cout: int) -> List[Tuple[int, int, int]]:
+    groups = (cout + 31) // 32
+    out = []
+    for mrep in (1, 2):
+        for nrep in (1, 2, 4):
+            if nrep > 1 and nrep // 2 >= groups:       # more than one empty 32-channel group
+                continue
+            for ck in (16, 32, 64):
+                if cin % ck == 0:
+                    out.append((mrep, nrep, ck))
+    return out
+
+
+def save(entries: Dict[str, Tuple[int, int, int]], path: str = PATH) -> None:
+    t = dict(table())
+    t.update({k_: list(v) for k_, v in entries.items()})
+    with open(path, "w") as f:
+        json.dump(dict(sorted(t.items())), f, indent=0)
+
+
+def main() -> None:
+    import argparse
+    import torch
+    from . import models
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="v5s")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--out", default=PATH)
+    args = ap.parse_args()
+    global enabled
+    enabled = False                                    # start every layer from the default rule
+    p, m = models.create(args.model)
+    dev = torch.device("cuda", 0)
+    prog = m.program()
+    imgs = torch.rand(args.batch, 3, p.img_size, p.img_size, device=dev)
+    prog.run(imgs)                                     # fill the buffers with real activations
+    best = prog.autotune(args.batch, dev, log=print)
+    save(best, args.out)
+    print(f"{len(best)} layer shapes -> {args.out}")
+
+
+if __name__ == "__main__":
+    main()
