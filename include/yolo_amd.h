@@ -57,15 +57,18 @@ typedef struct yamd_conv_desc {
     /* filled by yamd_conv_desc_init (kernel tiling; fixes the packed-weight layout) */
     int32_t nrep, ck, mrep, cout_pad;
     int64_t packed_w_elems;   /* bf16 elements of the packed weight blob */
+    int32_t nwaves;           /* 4 or 8 wavefronts per workgroup (they share one staged weight tile) */
+    int32_t reserved;
 } yamd_conv_desc;
 
 int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int cin, int cout, int act, int out_f32);
 
 /* Optional: override the tiling chosen by yamd_conv_desc_init (per-layer tuning) before the weights are packed.
  * mrep in {1,2}: 128 or 256 output pixels per workgroup; nrep in {1,2,4}: 32*nrep output channels per workgroup;
- * ck in {16,32,64}: input channels staged per step.  Fails if that kernel is not built.  No counterpart in the
- * reference (MIOpen picks its own algorithm there). */
-int yamd_conv_desc_tune(yamd_conv_desc *d, int mrep, int nrep, int ck);
+ * ck in {16,32,64}: input channels staged per step; nwaves in {4,8}: wavefronts per workgroup, i.e. the pixel tile
+ * is nwaves*32*mrep pixels.  Fails if that kernel is not built.  No counterpart in the reference (MIOpen picks its
+ * own algorithm there). */
+int yamd_conv_desc_tune(yamd_conv_desc *d, int mrep, int nrep, int ck, int nwaves);
 
 /* Host-side: fold nothing, just reorder.  w_oihw_host is float [cout][cin_real][k][k] (BN already
  * folded by the caller, cf. utils/torch_utils.py:344-370), bias_host float[cout] or NULL.

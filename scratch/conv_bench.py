@@ -7,8 +7,8 @@ B = int(sys.argv[6]) if len(sys.argv) > 6 else 256
 reps = int(sys.argv[7]) if len(sys.argv) > 7 else 20
 d = L.ConvDesc()
 L.check(L.LIB.yamd_conv_desc_init(ctypes.byref(d), k, s, cin, cout, 1, 0))
-if len(sys.argv) > 9:
-    L.check(L.LIB.yamd_conv_desc_tune(ctypes.byref(d), int(sys.argv[8]), int(sys.argv[9])))
+if len(sys.argv) > 11:
+    L.check(L.LIB.yamd_conv_desc_tune(ctypes.byref(d), *[int(v) for v in sys.argv[8:12]]))
 w = torch.randn(cout, cin, k, k) * 0.05
 b = torch.zeros(cout)
 wp = torch.empty(d.packed_w_elems, dtype=torch.int16); bp = torch.empty(d.cout_pad)

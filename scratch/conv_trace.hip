@@ -26,5 +26,5 @@ extern "C" int conv_trace_run(const void *x, int x_cs, const void *w, const floa
     p.n_tiles = ((cout + NREP * 32 - 1) / (NREP * 32)); p.nchunks = cin / CK;
     p.trace = trace;
     *grid_out = (int)(((long long)batch * p.tiles_y * p.tiles_x * p.n_tiles + 7) / 8 * 8);
-    return launch_conv<KS, S, TW, MREP, NREP, CK, false, YAMD_ACT_SILU>(p, batch, nullptr);
+    return launch_conv<KS, S, TW, MREP, NREP, CK, false, YAMD_ACT_SILU, 4>(p, batch, nullptr);
 }

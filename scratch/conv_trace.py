@@ -33,3 +33,5 @@ print(f"k{k}s{s} {cin}>{cout}@{Ho} blocks {len(t)}  total span {(t[:,4].max()-t[
 for i, n in enumerate(names):
     print(f"  {n:12s} mean {d_[:, i].mean():9.0f}  median {np.median(d_[:, i]):9.0f}  p90 {np.percentile(d_[:, i], 90):9.0f}")
 print(f"  block total  mean {(t[:,4]-t[:,0]).mean():9.0f}")
+if t[:, 7].min() > 0:
+    print(f"  chunk 1: issue+MFMA {np.median(t[:,6]-t[:,5]):8.0f}   barrier+write+barrier {np.median(t[:,7]-t[:,6]):8.0f}")

@@ -31,7 +31,7 @@ def _act(y, act):
     return y
 
 
-def _run_conv(dev, x, w, b, k, s, act, res=None, out_f32=False, in_extra=0, out_extra=0):
+def _run_conv(dev, x, w, b, k, s, act, res=None, out_f32=False, in_extra=0, out_extra=0, tiling=None):
     """x (B,Cin,H,W) fp32 (already bf16-representable); returns (B,Cout,Ho,Wo) fp32 from the HIP kernel.
     in_extra/out_extra: additional channels around the tensor inside a wider buffer (cstride test)."""
     from yolo_amd import lib as L
@@ -40,6 +40,8 @@ def _run_conv(dev, x, w, b, k, s, act, res=None, out_f32=False, in_extra=0, out_
     cin_st = (cin + 15) // 16 * 16
     d = L.ConvDesc()
     L.check(L.LIB.yamd_conv_desc_init(ctypes.byref(d), k, s, cin_st, cout, act, int(out_f32)))
+    if tiling is not None:
+        L.check(L.LIB.yamd_conv_desc_tune(ctypes.byref(d), *tiling))
     wp = torch.empty(d.packed_w_elems, dtype=torch.int16)
     bp = torch.empty(d.cout_pad, dtype=torch.float32)
     wc, bc = w.contiguous(), b.contiguous()
@@ -113,6 +115,51 @@ def test_conv_parity(gpu_device, k, s, cin, cout, H, W, act, use_res, out_f32):
     tol_l2, tol_abs = (1e-4, 1e-3) if out_f32 else (4e-3, 1.5e-2)
     assert rel_l2 <= tol_l2, f"rel L2 {rel_l2}"
     assert max_abs <= tol_abs * float(want.abs().max()), f"max abs {max_abs} vs {float(want.abs().max())}"
+
+
+TILING_CASES = [
+    # k, s, cin, cout, H, W, residual, (mrep, nrep, ck, nwaves): every tiling the per-layer tuner may pick
+    (1, 1, 64, 128, 40, 40, True, (1, 4, 32, 4)),
+    (1, 1, 64, 128, 23, 17, False, (1, 4, 64, 8)),
+    (1, 1, 128, 128, 40, 40, True, (2, 4, 64, 8)),
+    (1, 1, 64, 64, 32, 32, False, (1, 2, 64, 8)),
+    (1, 1, 64, 64, 20, 20, True, (2, 2, 64, 8)),
+    (1, 1, 64, 128, 20, 20, False, (1, 4, 32, 8)),
+    (1, 1, 64, 32, 20, 20, False, (1, 1, 64, 4)),
+    (3, 1, 64, 128, 40, 40, True, (2, 4, 16, 8)),
+    (3, 1, 64, 128, 19, 21, False, (1, 4, 16, 8)),
+    (3, 1, 64, 64, 32, 32, True, (2, 2, 32, 8)),
+    (3, 1, 64, 64, 20, 20, False, (1, 2, 32, 8)),
+    (3, 1, 32, 32, 40, 40, True, (1, 1, 32, 8)),
+    (3, 1, 32, 32, 16, 16, False, (2, 1, 16, 8)),
+    (3, 1, 64, 64, 20, 20, False, (1, 2, 32, 4)),
+    (3, 2, 64, 128, 40, 40, False, (1, 4, 16, 8)),
+    (3, 2, 64, 64, 31, 23, False, (1, 2, 16, 8)),
+    (3, 2, 64, 64, 32, 32, False, (1, 2, 32, 8)),
+    (3, 2, 64, 64, 40, 40, False, (1, 2, 16, 4)),
+    (3, 2, 64, 128, 40, 40, False, (2, 4, 16, 8)),
+    (3, 2, 64, 128, 37, 29, False, (2, 4, 16, 4)),
+    (3, 2, 32, 64, 64, 64, False, (2, 2, 16, 8)),
+    (3, 2, 32, 64, 23, 41, False, (2, 2, 16, 4)),
+]
+
+
+@pytest.mark.parametrize("k,s,cin,cout,H,W,use_res,tiling", TILING_CASES)
+def test_conv_tilings(gpu_device, k, s, cin, cout, H, W, use_res, tiling):
+    g = torch.Generator().manual_seed(k * 77 + cin + cout + H + sum(tiling))
+    Bn = 3
+    x = _bf16_round(torch.randn((Bn, cin, H, W), generator=g))
+    w = _bf16_round(torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+    b = torch.randn((cout,), generator=g) * 0.5
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    res = _bf16_round(torch.randn((Bn, cout, Ho, Wo), generator=g)) if use_res else None
+    want = _act(F.conv2d(x, w, b, stride=s, padding=k // 2), 1)
+    if res is not None:
+        want = want + res
+    got = _run_conv(gpu_device, x, w, b, k, s, 1, res, False, in_extra=16, out_extra=8, tiling=tiling)
+    err = (got - want).double()
+    assert float(err.norm() / want.double().norm()) <= 4e-3
+    assert float(err.abs().max()) <= 1.5e-2 * float(want.abs().max())
 
 
 def test_conv_identity_asymmetric(gpu_device):

@@ -4,9 +4,9 @@
 using namespace yamd;
 
 namespace yamd {
-int conv_dispatch_k1(const ConvParams &p, int batch, int tw, int mrep, int nrep, int ck, int f32, hipStream_t st);
-int conv_dispatch_k3s1(const ConvParams &p, int batch, int tw, int mrep, int nrep, int ck, int f32, hipStream_t st);
-int conv_dispatch_k3s2(const ConvParams &p, int batch, int tw, int mrep, int nrep, int ck, int f32, hipStream_t st);
+int conv_dispatch_k1(const ConvParams &p, int batch, int tw, int mrep, int nrep, int ck, int f32, int nwaves, hipStream_t st);
+int conv_dispatch_k3s1(const ConvParams &p, int batch, int tw, int mrep, int nrep, int ck, int f32, int nwaves, hipStream_t st);
+int conv_dispatch_k3s2(const ConvParams &p, int batch, int tw, int mrep, int nrep, int ck, int f32, int nwaves, hipStream_t st);
 }  // namespace yamd
 
 extern "C" int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int cin, int cout, int act, int out_f32)
@@ -26,6 +26,7 @@ extern "C" int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int
     d->out_f32 = out_f32 ? 1 : 0;
     const int groups = (cout + 31) / 32;
     d->mrep = (stride == 2) ? 1 : 2;
+    d->nwaves = 4;
     if (out_f32) {
         YAMD_REQUIRE(ksize == 1 && cin % 64 == 0, "float output is only built for 1x1 convs with cin %% 64 == 0");
         d->nrep = 4;
@@ -64,19 +65,29 @@ extern "C" int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int
     return YAMD_OK;
 }
 
-extern "C" int yamd_conv_desc_tune(yamd_conv_desc *d, int mrep, int nrep, int ck)
+extern "C" int yamd_conv_desc_tune(yamd_conv_desc *d, int mrep, int nrep, int ck, int nwaves)
 {
     YAMD_REQUIRE(d != nullptr, "null descriptor");
+    YAMD_REQUIRE(nwaves == 4 || nwaves == 8, "nwaves=%d must be 4 or 8", nwaves);
     YAMD_REQUIRE((mrep == 1 || mrep == 2) && (nrep == 1 || nrep == 2 || nrep == 4) && (ck == 16 || ck == 32 || ck == 64),
                  "bad tiling mrep=%d nrep=%d ck=%d", mrep, nrep, ck);
     YAMD_REQUIRE(d->cin % ck == 0, "cin=%d is not a multiple of ck=%d", d->cin, ck);
     YAMD_REQUIRE(!d->out_f32, "the float-output kernel has one tiling");
     bool built;
-    if (d->ksize == 1) built = ck >= 32;
-    else if (d->stride == 1) built = (ck == 16 && (nrep == 1 || nrep == 4)) || (ck == 32 && (nrep == 1 || nrep == 2));
-    else built = mrep == 1 && ((ck == 16) || (ck == 32 && nrep == 2));
-    YAMD_REQUIRE(built, "no kernel built for k=%d s=%d mrep=%d nrep=%d ck=%d", d->ksize, d->stride, mrep, nrep, ck);
+    if (d->ksize == 1) {
+        built = ck >= 32;
+        if (nwaves == 8)
+            built = (nrep == 4 && ck == 64) || (mrep == 1 && nrep == 4 && ck == 32) || (nrep == 2 && ck == 64);
+    } else if (d->stride == 1) {
+        built = (ck == 16 && (nrep == 1 || nrep == 4)) || (ck == 32 && (nrep == 1 || nrep == 2));
+    } else {
+        built = (mrep == 1 && ((ck == 16) || (ck == 32 && nrep == 2))) || (mrep == 2 && ck == 16 && nrep >= 2);
+        if (nwaves == 8) built = built && nrep >= 2;
+    }
+    YAMD_REQUIRE(built, "no kernel built for k=%d s=%d mrep=%d nrep=%d ck=%d nwaves=%d", d->ksize, d->stride, mrep, nrep,
+                 ck, nwaves);
     d->mrep = mrep;
+    d->nwaves = nwaves;
     d->nrep = nrep;
     d->ck = ck;
     const int bn = nrep * 32;
@@ -161,7 +172,7 @@ extern "C" int yamd_conv2d_bias_act(const yamd_conv_desc *d, const void *x, int 
     p.Cout = d->cout;
     p.act = d->act;
     const int TW = pick_tw(p.Wout);
-    const int th_max = (128 * d->mrep) / TW;
+    const int th_max = (d->nwaves * 32 * d->mrep) / TW;
     p.tiles_x = ceil_div(p.Wout, TW);
     p.tiles_y = ceil_div(p.Hout, th_max);
     p.TH = ceil_div(p.Hout, p.tiles_y);
@@ -170,11 +181,11 @@ extern "C" int yamd_conv2d_bias_act(const yamd_conv_desc *d, const void *x, int 
     hipStream_t st = (hipStream_t)stream;
 
     int rc = 1;
-    if (KS == 1) rc = conv_dispatch_k1(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, st);
-    else if (S == 1) rc = conv_dispatch_k3s1(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, st);
-    else rc = conv_dispatch_k3s2(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, st);
+    if (KS == 1) rc = conv_dispatch_k1(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, d->nwaves, st);
+    else if (S == 1) rc = conv_dispatch_k3s1(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, d->nwaves, st);
+    else rc = conv_dispatch_k3s2(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, d->nwaves, st);
     if (rc <= 0) return rc;
-    set_error("no conv kernel built for k=%d s=%d mrep=%d nrep=%d ck=%d f32=%d", KS, S, d->mrep, d->nrep, d->ck,
-              d->out_f32);
+    set_error("no conv kernel built for k=%d s=%d mrep=%d nrep=%d ck=%d f32=%d nwaves=%d", KS, S, d->mrep, d->nrep,
+              d->ck, d->out_f32, d->nwaves);
     return YAMD_EINVAL;
 }

@@ -96,9 +96,10 @@ __device__ __forceinline__ void act4(float (&v)[4])
     for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], ACT);
 }
 
-template <int KS, int S, int TW, int MREP, int NREP, int CK, bool OUT_F32, int ACTK>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
+template <int KS, int S, int TW, int MREP, int NREP, int CK, bool OUT_F32, int ACTK, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_kernel(ConvParams p)
 {
+    constexpr int NT = NW * 64;              // threads per workgroup (4 or 8 waves share one weight tile)
     constexpr int PAD = KS / 2;
     constexpr int NPW = (TW - 1) * S + KS;   // halo width in input pixels
     constexpr int NPWH = (NPW + 1) / 2;      // even-column count (stride-2 de-interleave)
@@ -143,10 +144,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
 
     // Staging registers: the next chunk's global loads are issued before the current chunk is computed
     // and written to LDS afterwards, so HBM/L2 latency hides under the MFMA work.
-    constexpr int THMAX = (128 * MREP) / TW;
+    constexpr int THMAX = (NW * 32 * MREP) / TW;
     constexpr int NPHMAX = (THMAX - 1) * S + KS;
-    constexpr int AP = (NPHMAX * NPW * G8 + 255) / 256;   // activation pieces per thread
-    constexpr int WP = (WBYTES / 16 + 255) / 256;         // weight pieces per thread
+    constexpr int AP = (NPHMAX * NPW * G8 + NT - 1) / NT;   // activation pieces per thread
+    constexpr int WP = (WBYTES / 16 + NT - 1) / NT;         // weight pieces per thread
     u32x4 ra[AP], rw[WP];
     const int total = NPH * NPW * G8;
 
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
     unsigned inb_mask = 0u;
     static_for<AP>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value;
-        const int q = min(tid + u * 256, total - 1);
+        const int q = min(tid + u * NT, total - 1);
         const int pix = q / G8, gc = q % G8;
         const int hr = pix / NPW, hc = pix % NPW;
         const int ih = oh0 * S - PAD + hr, iw = ow0 * S - PAD + hc;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
         const char *wsrc = wtile + (size_t)ch * WBYTES;
         static_for<WP>([&](auto uc) __attribute__((always_inline)) {
             constexpr int u = decltype(uc)::value;
-            const int q = min(tid + u * 256, WBYTES / 16 - 1);
+            const int q = min(tid + u * NT, WBYTES / 16 - 1);
             rw[u] = *(const u32x4 *)(wsrc + q * 16);
         });
         const __bf16 *xc = ximg + ch * CK;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
     auto write_lds = [&]() __attribute__((always_inline)) {
         static_for<WP>([&](auto uc) __attribute__((always_inline)) {
             constexpr int u = decltype(uc)::value;
-            const int q = min(tid + u * 256, WBYTES / 16 - 1);
+            const int q = min(tid + u * NT, WBYTES / 16 - 1);
             *(u32x4 *)(ldsW + q * 16) = rw[u];
         });
         static_for<AP>([&](auto uc) __attribute__((always_inline)) {
@@ -217,6 +218,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
     YAMD_STAMP(2);
     for (int ch = 0; ch < p.nchunks; ++ch) {
         const bool more = ch + 1 < p.nchunks;
+#ifdef YAMD_CONV_TRACE
+        if (ch == 1) YAMD_STAMP(5);
+#endif
         if (more) issue_loads(ch + 1);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
@@ -237,11 +241,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[n], a[m], acc[m][n], 0, 0, 0);
             }
         }
+#ifdef YAMD_CONV_TRACE
+        if (ch == 1) YAMD_STAMP(6);
+#endif
         __syncthreads();   // every wave is done reading this chunk
         if (more) {
             write_lds();
             __syncthreads();
         }
+#ifdef YAMD_CONV_TRACE
+        if (ch == 1) YAMD_STAMP(7);
+#endif
     }
 
     YAMD_STAMP(3);
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p)
     YAMD_STAMP(4);
 }
 
-template <int KS, int S, int TW, int MREP, int NREP, int CK, bool OUT_F32, int ACTK>
+template <int KS, int S, int TW, int MREP, int NREP, int CK, bool OUT_F32, int ACTK, int NW = 4>
 int launch_conv(const ConvParams &p, int batch, hipStream_t stream)
 {
     constexpr int NPW = (TW - 1) * S + KS;
@@ -359,9 +369,9 @@ int launch_conv(const ConvParams &p, int batch, hipStream_t stream)
     constexpr int WBYTES = KS * KS * (CK / 16) * NREP * 1024;
     const int NPH = (p.TH - 1) * S + KS;
     size_t lds = (size_t)WBYTES + (size_t)NPH * NPW * RS;
-    if (!OUT_F32 && lds < (size_t)4 * 32 * (NREP * 64 + 16)) lds = (size_t)4 * 32 * (NREP * 64 + 16);
+    if (!OUT_F32 && lds < (size_t)NW * 32 * (NREP * 64 + 16)) lds = (size_t)NW * 32 * (NREP * 64 + 16);
     YAMD_REQUIRE(lds <= 160 * 1024, "conv tile needs %zu bytes of LDS", lds);
-    auto kern = conv_igemm_kernel<KS, S, TW, MREP, NREP, CK, OUT_F32, ACTK>;
+    auto kern = conv_igemm_kernel<KS, S, TW, MREP, NREP, CK, OUT_F32, ACTK, NW>;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [&] {
@@ -373,24 +383,24 @@ int launch_conv(const ConvParams &p, int batch, hipStream_t stream)
     ConvParams q = p;
     q.total_tiles = (int)total;
     const long long grid = (total + 7) / 8 * 8;      // a multiple of the XCD count; surplus workgroups exit at once
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, q);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NW * 64), lds, stream, q);
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
 }
 
 // one tiling, both tile widths, SiLU-specialised or run-time activation
-template <int KS, int S, int MREP, int NREP, int CK, bool OUT_F32>
+template <int KS, int S, int MREP, int NREP, int CK, bool OUT_F32, int NW = 4>
 int launch_conv_variant(const ConvParams &p, int batch, int tw, hipStream_t st)
 {
     if constexpr (OUT_F32) {
-        return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, true, -1>(p, batch, st)
-                        : launch_conv<KS, S, 20, MREP, NREP, CK, true, -1>(p, batch, st);
+        return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, true, -1, NW>(p, batch, st)
+                        : launch_conv<KS, S, 20, MREP, NREP, CK, true, -1, NW>(p, batch, st);
     } else {
         if (p.act == YAMD_ACT_SILU)
-            return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, false, YAMD_ACT_SILU>(p, batch, st)
-                            : launch_conv<KS, S, 20, MREP, NREP, CK, false, YAMD_ACT_SILU>(p, batch, st);
-        return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, false, -1>(p, batch, st)
-                        : launch_conv<KS, S, 20, MREP, NREP, CK, false, -1>(p, batch, st);
+            return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, false, YAMD_ACT_SILU, NW>(p, batch, st)
+                            : launch_conv<KS, S, 20, MREP, NREP, CK, false, YAMD_ACT_SILU, NW>(p, batch, st);
+        return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, false, -1, NW>(p, batch, st)
+                        : launch_conv<KS, S, 20, MREP, NREP, CK, false, -1, NW>(p, batch, st);
     }
 }
 

@@ -32,7 +32,7 @@ class ConvLayer:
     """One fused conv: descriptor + packed weights (host copies kept so any device can be fed)."""
 
     def __init__(self, name: str, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, act: int,
-                 cin_stored: int, out_f32: bool, tiling: Optional[Tuple[int, int, int]] = None):
+                 cin_stored: int, out_f32: bool, tiling: Optional[Tuple[int, ...]] = None):
         w = weight.detach().to(torch.float32).cpu().contiguous()
         cout, cin_real, k, k2 = w.shape
         assert k == k2
@@ -44,7 +44,7 @@ class ConvLayer:
         self._args = (k, stride, cin_stored, cout, act, int(out_f32))
         self.pack(tiling)
 
-    def pack(self, tiling: Optional[Tuple[int, int, int]] = None) -> None:
+    def pack(self, tiling: Optional[Tuple[int, ...]] = None) -> None:
         """(Re)build the descriptor and the packed weights; ``tiling`` = (mrep, nrep, ck) overrides the default."""
         name = self.name
         self.desc = _lib.ConvDesc()
@@ -61,8 +61,8 @@ class ConvLayer:
         self.b_dev: Optional[torch.Tensor] = None
 
     @property
-    def tiling(self) -> Tuple[int, int, int]:
-        return (self.desc.mrep, self.desc.nrep, self.desc.ck)
+    def tiling(self) -> Tuple[int, int, int, int]:
+        return (self.desc.mrep, self.desc.nrep, self.desc.ck, self.desc.nwaves)
 
     def to(self, device) -> None:
         if self.w_dev is None or self.w_dev.device != torch.device(device):
@@ -194,13 +194,13 @@ class Program:
         return buf, coff
 
     # ---- per-layer tiling search ------------------------------------------------------------------
-    def autotune(self, batch: int, device, reps: int = 5, log=None) -> Dict[str, Tuple[int, int, int]]:
+    def autotune(self, batch: int, device, reps: int = 5, log=None) -> Dict[str, Tuple[int, ...]]:
         """Times every built tiling of every bf16 conv on this program's own buffers and keeps the fastest.
         Returns {tuning key: (mrep, nrep, ck)} for ``tuning.save``."""
         from . import tuning
         bufs = self._buffers_for(batch, device)
         st = _lib.current_stream()
-        best: Dict[str, Tuple[int, int, int]] = {}
+        best: Dict[str, Tuple[int, ...]] = {}
         for op in self.ops:
             if op[0] != "conv" or op[1].desc.out_f32:
                 continue

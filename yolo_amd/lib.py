@@ -28,7 +28,7 @@ class ConvDesc(ctypes.Structure):
     """Mirror of ``yamd_conv_desc``."""
     _fields_ = [("ksize", c_int32), ("stride", c_int32), ("cin", c_int32), ("cout", c_int32), ("act", c_int32),
                 ("out_f32", c_int32), ("nrep", c_int32), ("ck", c_int32), ("mrep", c_int32), ("cout_pad", c_int32),
-                ("packed_w_elems", c_int64)]
+                ("packed_w_elems", c_int64), ("nwaves", c_int32), ("reserved", c_int32)]
 
 
 class YamdError(RuntimeError):
@@ -49,7 +49,7 @@ def _load() -> ctypes.CDLL:
     lib.yamd_last_error.argtypes = []
     lib.yamd_version.restype = c_int
     lib.yamd_conv_desc_init.argtypes = [P(ConvDesc), c_int, c_int, c_int, c_int, c_int, c_int]
-    lib.yamd_conv_desc_tune.argtypes = [P(ConvDesc), c_int, c_int, c_int]
+    lib.yamd_conv_desc_tune.argtypes = [P(ConvDesc), c_int, c_int, c_int, c_int]
     lib.yamd_conv_pack_weights.argtypes = [P(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p]
     lib.yamd_conv2d_bias_act.argtypes = [P(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                          c_int, c_int, c_int, c_int, c_void_p]

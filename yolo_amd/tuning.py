@@ -26,14 +26,16 @@ def table() -> Dict[str, List[int]]:
     return _table
 
 
-def lookup(k: int, s: int, cin: int, cout: int, ho: int, wo: int) -> Optional[Tuple[int, int, int]]:
+def lookup(k: int, s: int, cin: int, cout: int, ho: int, wo: int) -> Optional[Tuple[int, ...]]:
     if not enabled:
         return None
     t = table().get(key(k, s, cin, cout, ho, wo))
-    return None if t is None else (int(t[0]), int(t[1]), int(t[2]))
+    if t is None:
+        return None
+    return (int(t[0]), int(t[1]), int(t[2]), int(t[3]) if len(t) > 3 else 4)
 
 
-def candidates(k: int, s: int, cin: int, cout: int) -> List[Tuple[int, int, int]]:
+def candidates(k: int, s: int, cin: int, cout: int) -> List[Tuple[int, ...]]:
     groups = (cout + 31) // 32
     out = []
     for mrep in (1, 2):
@@ -42,11 +44,12 @@ def candidates(k: int, s: int, cin: int, cout: int) -> List[Tuple[int, int, int]
                 continue
             for ck in (16, 32, 64):
                 if cin % ck == 0:
-                    out.append((mrep, nrep, ck))
+                    out.append((mrep, nrep, ck, 4))
+                    out.append((mrep, nrep, ck, 8))
     return out
 
 
-def save(entries: Dict[str, Tuple[int, int, int]], path: str = PATH) -> None:
+def save(entries: Dict[str, Tuple[int, ...]], path: str = PATH) -> None:
     t = dict(table())
     t.update({k_: list(v) for k_, v in entries.items()})
     with open(path, "w") as f:
