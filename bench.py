@@ -209,6 +209,22 @@ def stage_profile(model, p, images, reps=3):
                 nms_ms=nms_ms, other_ms=sum(r["ms"] for r in table if r["kind"] != "conv"))
 
 
+def measured_conv_traffic(model_name: str, batch: int, n_conv: int):
+    """HBM bytes per conv launch from the committed PMC passes (profiles/*_conv_hbm_traffic.json, written by
+    scratch/pmc_conv.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command): counters cannot be
+    read from inside the process, so the latest committed measurement of the same workload is reported."""
+    import glob
+    if model_name != "v5s" or batch != 256:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_conv_hbm_traffic.json")))
+    for f in reversed(files):
+        with open(f) as fh:
+            d = json.load(fh)
+        if d.get("convs_per_pass") == n_conv:
+            return float(d["bytes_per_launch"]), os.path.relpath(f, ROOT)
+    return None, None
+
+
 def cpu_baseline(name, sd, p, n_images):
     """The CPU oracle (torch fp32 graph + numpy decode + C NMS) timed on the host cores: reported baseline."""
     from oracle import graphs_ref, postprocess
@@ -282,6 +298,7 @@ def main():
         pred = model.decode_predict(model.raw_heads(images[:8]))
         ncls = p.class_num
         cand = ((pred[..., 4] * pred[..., -ncls:].max(-1).values) >= p.conf_threshold).sum(1).float().mean().item()
+        traffic, traffic_src = measured_conv_traffic(args.model, B, prof["n_conv"])
         out = {
             "metric": METRIC, "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
@@ -294,7 +311,8 @@ def main():
                        "candidates_per_image": round(cand, 1), "kept_per_image": round(float(counts.mean()), 1),
                        "kept_max": int(counts.max())},
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(conv_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(conv_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
                          "kernel": "conv_igemm_kernel (all %d fused conv launches of one step)" % prof["n_conv"],
                          "flops_per_launch": prof["conv_flops"] / prof["n_conv"],
                          "avg_launch_ms": round(prof["conv_ms"] / prof["n_conv"], 4)},
