@@ -42,7 +42,7 @@ def _match_rows_abs(got, want, tol):
 def _model(name, size, seed):
     from yolo_amd import models
     from yolo_amd.init import seeded_state_dict
-    p, m = models.create(name, size)
+    p, m = models.create(name, size)          # size 0: the model's BASELINE image size
     sd = seeded_state_dict(m, seed=seed, mode="spread", **models.init_options(name))
     m.load_state_dict(sd, strict=True)
     return p, m, sd
@@ -157,3 +157,40 @@ def test_yolo_predict_entry_points(gpu_device, tmp_path):
     want = tu.non_max_suppression_with_point_conf(pred, 64, 17, "cxcywh", 0.3, 0.3)
     for a, b in zip(got, want):
         assert (a is None and b is None) or np.array_equal(a, b.cpu().numpy())
+
+
+FULL = {"v8s": 128, "v3": 256, "v4": 256, "v7pose": 512, "v6face": 512}     # BASELINE per-GPU batch sizes
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_full_batch_properties(name, gpu_device):
+    """BASELINE image size and per-GPU batch: size-independent properties of the whole path -- the position in the
+    batch does not matter (replicated images give bit-identical rows), rows come in descending score order, and
+    the kept rows of two images equal the C oracle's NMS of the same decoded tensor bit for bit."""
+    from oracle import graphs_ref, postprocess as pp
+    from yolo_amd import models
+    from yolo_amd.init import seeded_images
+    p, m, _ = _model(name, 0, 41)
+    B, S = FULL[name], p.img_size
+    base = torch.from_numpy(seeded_images(8, S, seed=41)).to(gpu_device)
+    imgs = base.repeat(B // 8, 1, 1, 1)
+    pred = m.decode_predict(m.raw_heads(imgs))
+    rows, counts = m.nms_predict(pred)
+    assert pred.shape[0] == B and rows.shape[0] == B
+    counts = counts.cpu().numpy()
+    assert (counts.reshape(B // 8, 8) == counts[:8]).all()
+    r0, r1 = rows[:8].cpu().numpy(), rows[B - 8:].cpu().numpy()
+    for b in range(8):
+        k = counts[b]
+        assert np.array_equal(r0[b, :k].view(np.uint32), r1[b, :k].view(np.uint32))
+        sc = r0[b, :k, 4] * r0[b, :k, 5]
+        assert (np.diff(sc) <= 0).all(), "rows must be in descending score order"
+    ref = graphs_ref.model_ref(name)
+    want = pp.non_max_suppression(pred[:2].cpu().numpy(), S, conf_threshold=p.conf_threshold,
+                                  nms_threshold=p.nms_threshold, **ref["nms"])
+    for b in range(2):
+        if want[b] is None:
+            assert counts[b] == 0
+            continue
+        assert counts[b] == want[b].shape[0]
+        assert np.array_equal(r0[b, :counts[b]].view(np.uint32), want[b].view(np.uint32))
