@@ -17,6 +17,7 @@ struct AnchorDecodeParams {
     const float *raw;
     float *out;
     int H, W, na, C, kind, P, stride, merge, clamp_points;
+    unsigned c_magic;         // ceil(2^22 / C): e / C == (e * c_magic) >> 22 for e * C < 2^22
     float hi;                 // img_size - 1
     float aw[8], ah[8];       // anchor / stride, fp32 division as torch does it
     long long rows_per_image, row_offset;
@@ -24,11 +25,17 @@ struct AnchorDecodeParams {
 
 __device__ __forceinline__ float sigmoidf_exact(float t) { return 1.0f / (1.0f + expf(-t)); }
 
+// Hardware exp2 / reciprocal (about 1 ulp each): sigmoid and exp within a few 1e-7 relative of the correctly
+// rounded functions for the logit range of a detector head, far inside the 1e-5 the decode is held to.
+__device__ __forceinline__ float fast_exp(float t) { return __builtin_amdgcn_exp2f(t * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_sigmoid(float t) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-t)); }
+
 __global__ __launch_bounds__(256) void decode_anchor_kernel(AnchorDecodeParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) float sraw[];
+    extern __shared__ __attribute__((aligned(16))) float sraw[];     // PIX*na*C logits, then the grid x / y of the pixels
     const int HW = p.H * p.W;
     const int naC = p.na * p.C;
+    float *sgx = sraw + PIX * naC, *sgy = sgx + PIX;
     const int p0 = blockIdx.x * PIX;
     const int np = min(PIX, HW - p0);
     const long long b = blockIdx.y;
@@ -41,43 +48,42 @@ __global__ __launch_bounds__(256) void decode_anchor_kernel(AnchorDecodeParams p
     } else {
         for (int i = threadIdx.x; i < total; i += 256) sraw[i] = src[i];
     }
+    if (threadIdx.x < PIX) {
+        const int gp = p0 + threadIdx.x;
+        sgx[threadIdx.x] = (float)(gp % p.W);
+        sgy[threadIdx.x] = (float)(gp / p.W);
+    }
     __syncthreads();
 
-    const int cl = threadIdx.x & 31;    // column lane
-    const int rl = threadIdx.x >> 5;    // 8 rows in flight
+    // The np rows of one anchor are one contiguous run of np*C floats in the output: thread t writes elements
+    // t, t+256, ... of that run, so every store instruction covers whole cache lines and no lane idles.
     const float fs = (float)p.stride;
-    for (int r = rl; r < p.na * PIX; r += 8) {
-        const int a = r / PIX, pix = r % PIX;
-        if (pix >= np) continue;
-        const int gp = p0 + pix;
-        const float gx = (float)(gp % p.W), gy = (float)(gp / p.W);
+    const int pe = 5 + 2 * p.P;
+    const int run = np * p.C;
+    for (int a = 0; a < p.na; ++a) {
         const float aw = p.aw[a], ah = p.ah[a];
-        const float *row = sraw + pix * naC + a * p.C;
-        float *dst = p.out + ((b * p.rows_per_image + p.row_offset + (long long)a * HW + gp) * p.C);
-        for (int c = cl; c < p.C; c += 32) {
-            const float t = row[c];
+        float *dst = p.out + ((b * p.rows_per_image + p.row_offset + (long long)a * HW + p0) * p.C);
+        for (int e = threadIdx.x; e < run; e += 256) {
+            const int pix = (int)(((unsigned)e * p.c_magic) >> 22);      // e / C (exact for e*C < 2^22)
+            const int c = e - pix * p.C;
+            const float t = sraw[pix * naC + a * p.C + c];
+            const float gx = sgx[pix], gy = sgy[pix];
             float v;
-            bool is_box = c < 4, is_pt = false;
+            const bool is_box = c < 4;
+            bool is_pt = false;
             if (p.kind == YAMD_DECODE_V3) {
-                if (c == 0) v = sigmoidf_exact(t) + gx;
-                else if (c == 1) v = sigmoidf_exact(t) + gy;
-                else if (c == 2) v = expf(t) * aw;
-                else if (c == 3) v = expf(t) * ah;
-                else v = sigmoidf_exact(t);
+                const float s = fast_sigmoid(t), ex = fast_exp(t);
+                v = c == 0 ? s + gx : (c == 1 ? s + gy : (c == 2 ? ex * aw : (c == 3 ? ex * ah : s)));
             } else {
-                const int pe = 5 + 2 * p.P;
                 if (c >= 5 && c < pe && p.kind != YAMD_DECODE_V5) {
                     is_pt = true;
                     const bool isx = ((c - 5) & 1) == 0;
                     if (p.kind == YAMD_DECODE_POSE) v = (2.0f * t - 0.5f) + (isx ? gx : gy);
                     else v = t * (isx ? aw : ah) + (isx ? gx : gy);
                 } else {
-                    const float s = sigmoidf_exact(t);
-                    if (c == 0) v = 2.0f * s - 0.5f + gx;
-                    else if (c == 1) v = 2.0f * s - 0.5f + gy;
-                    else if (c == 2) { const float w2 = 2.0f * s; v = (w2 * w2) * aw; }
-                    else if (c == 3) { const float h2 = 2.0f * s; v = (h2 * h2) * ah; }
-                    else v = s;
+                    const float s = fast_sigmoid(t);
+                    const float s2 = 2.0f * s;
+                    v = c == 0 ? s2 - 0.5f + gx : (c == 1 ? s2 - 0.5f + gy : (c == 2 ? (s2 * s2) * aw : (c == 3 ? (s2 * s2) * ah : s)));
                 }
             }
             if (p.merge) {
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256) void decode_anchor_kernel(AnchorDecodeParams p
                     if (p.clamp_points) v = fminf(fmaxf(v, 0.0f), p.hi);
                 }
             }
-            dst[c] = v;
+            dst[e] = v;
         }
     }
 }
@@ -232,8 +238,11 @@ extern "C" int yamd_decode_anchor(int kind, const float *raw, int batch, int h, 
     YAMD_REQUIRE(batch > 0 && batch <= 65535 && h > 0 && w > 0 && na > 0 && na <= 8 && stride > 0, "bad shape");
     const int need = (kind == YAMD_DECODE_POSE) ? 5 + 3 * point_num + 1 : (kind == YAMD_DECODE_FACE ? 5 + 2 * point_num + 1 : 6);
     YAMD_REQUIRE(c >= need && point_num >= 0, "c=%d too small for kind %d with %d points", c, kind, point_num);
-    const size_t lds = (size_t)PIX * na * c * sizeof(float);
-    YAMD_REQUIRE(lds <= 64 * 1024, "na*c=%d too large for the decode tile", na * c);
+    const size_t lds = (size_t)PIX * (na * c + 2) * sizeof(float);
+    YAMD_REQUIRE(lds <= 160 * 1024 && (long long)PIX * c * c < (1ll << 22), "na*c=%d too large for the decode tile", na * c);
+    static hipError_t attr_err = hipFuncSetAttribute((const void *)decode_anchor_kernel,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    YAMD_HIP(attr_err);
     AnchorDecodeParams p;
     p.raw = raw;
     p.out = out;
@@ -243,6 +252,7 @@ extern "C" int yamd_decode_anchor(int kind, const float *raw, int batch, int h, 
     p.C = c;
     p.kind = kind;
     p.P = point_num;
+    p.c_magic = (unsigned)(((1u << 22) + (unsigned)c - 1u) / (unsigned)c);
     p.stride = stride;
     p.merge = merge ? 1 : 0;
     p.clamp_points = clamp_points ? 1 : 0;
