@@ -257,25 +257,37 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_kernel(Co
     YAMD_STAMP(3);
     // epilogue: lane holds, for pixel c32 of each fragment, couts 8*i + 4*g + j (i,j = 0..3)
     if constexpr (OUT_F32) {
+        // float logits also go through a per-wave LDS tile [32 pixels][BN couts]: the global stores then walk the
+        // channels of one pixel (Cout*4 contiguous bytes) with consecutive lanes instead of one pixel per lane
+        constexpr int RSF = NREP * 128 + 16;       // bytes per pixel row of the staging tile
+        char *wreg = smem + wave * (32 * RSF);     // the chunk loop ended with a barrier: LDS is free
 #pragma unroll
         for (int m = 0; m < MREP; ++m) {
-            const int pp = wave * (32 * MREP) + m * 32 + c32;
-            const int pr = pp / TW, pc = pp % TW;
-            const int oh = oh0 + pr, ow = ow0 + pc;
-            const bool valid = pr < p.TH && oh < p.Hout && ow < p.Wout;
-            const size_t pix = (size_t)(b * p.Hout + oh) * p.Wout + ow;
 #pragma unroll
             for (int n = 0; n < NREP; ++n) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int co = nt * (NREP * 32) + n * 32 + 8 * i + 4 * g;
-                    if (!valid || co >= p.Cout) continue;
-                    float *y = (float *)p.y + pix * p.y_cs + co;
+                    const int cl = n * 32 + 8 * i + 4 * g;
+                    f32x4 v;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (co + j < p.Cout) y[j] = apply_act(acc[m][n][4 * i + j], p.act);
+                    for (int j = 0; j < 4; ++j) v[j] = apply_act(acc[m][n][4 * i + j], p.act);
+                    *(f32x4 *)(wreg + c32 * RSF + cl * 4) = v;
                 }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            for (int r = 0; r < 32; ++r) {
+                const int pq = wave * (32 * MREP) + m * 32 + r;
+                const int qr = pq / TW, qc = pq % TW;
+                if (!(qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)) continue;      // uniform in the wave
+                float *y = (float *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + nt * (NREP * 32);
+                const int nco = min(NREP * 32, p.Cout - nt * (NREP * 32));
+#pragma unroll
+                for (int c = lane; c < NREP * 32; c += 64)
+                    if (c < nco) y[c] = *(const float *)(wreg + r * RSF + c * 4);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
     } else {
         // bf16 output goes through a per-wave LDS tile [32 pixels][BN couts] so that the global stores are
@@ -369,7 +381,8 @@ int launch_conv(const ConvParams &p, int batch, hipStream_t stream)
     constexpr int WBYTES = KS * KS * (CK / 16) * NREP * 1024;
     const int NPH = (p.TH - 1) * S + KS;
     size_t lds = (size_t)WBYTES + (size_t)NPH * NPW * RS;
-    if (!OUT_F32 && lds < (size_t)NW * 32 * (NREP * 64 + 16)) lds = (size_t)NW * 32 * (NREP * 64 + 16);
+    const size_t epi = (size_t)NW * 32 * (OUT_F32 ? NREP * 128 + 16 : NREP * 64 + 16);   // epilogue staging tiles
+    if (lds < epi) lds = epi;
     YAMD_REQUIRE(lds <= 160 * 1024, "conv tile needs %zu bytes of LDS", lds);
     auto kern = conv_igemm_kernel<KS, S, TW, MREP, NREP, CK, OUT_F32, ACTK, NW>;
     static std::once_flag once;
