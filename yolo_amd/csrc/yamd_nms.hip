@@ -479,6 +479,8 @@ __global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
 // thread binary-searches its own key there.
 constexpr int GATHER_THREADS = 1024;
 constexpr int GATHER_CHUNK = 2048;
+constexpr int GSORT_CAP = 16384;     // kept rows per image the LDS gather handles (128 KB of keys)
+constexpr int GSORT_MAXC = 256;      // ... and classes
 __global__ __launch_bounds__(GATHER_THREADS) void nms_gather_kernel(NmsParams p)
 {
     __shared__ u64 lk[GATHER_CHUNK];
@@ -494,6 +496,11 @@ __global__ __launch_bounds__(GATHER_THREADS) void nms_gather_kernel(NmsParams p)
     }
     const u32 mine = kcnt[cls];
     if (mine == 0) return;
+    {
+        u32 s = 0;
+        for (int c = 0; c < p.nc; ++c) s += kcnt[c];
+        if (s <= (u32)GSORT_CAP && p.nc <= GSORT_MAXC) return;     // nms_gather_sort_kernel writes this image
+    }
     const u64 *kbase = p.kseg + b * p.A;
     for (u32 i0 = 0; i0 < mine; i0 += GATHER_THREADS) {
         const u32 i = i0 + tid;
@@ -531,6 +538,121 @@ __global__ __launch_bounds__(GATHER_THREADS) void nms_gather_kernel(NmsParams p)
         for (int e = 0; e < p.n_extra; ++e) o[6 + e] = row[5 + e];
         o[p.W - 1] = (float)bi;
         if (p.out_index) p.out_index[b * p.max_out + rank] = (int)idx;
+    }
+}
+
+// Gather for images with at most GSORT_CAP kept rows (the common case): one workgroup per image holds the kept keys of
+// all classes in LDS (each class list is already in descending order).  The global rank of a key is its index in
+// its own list plus, for every other class, the number of keys greater than it (binary search in LDS, no chunking).
+// The keys are stored in rank order for nms_rows_kernel.
+__global__ __launch_bounds__(GATHER_THREADS) void nms_gather_sort_kernel(NmsParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) u64 gk[];             // the kept keys of the image, class after class
+    __shared__ u32 cpos[GSORT_MAXC + 1];
+    const long long b = blockIdx.x;
+    const u32 *kcnt = p.kcnt + b * p.nc;
+    const u32 *coff = p.cls_off + b * (p.nc + 1);
+    const int tid = threadIdx.x;
+    if (p.nc > GSORT_MAXC) return;                      // uniform: nms_gather_kernel takes over
+    u32 total = 0;
+    for (int c = 0; c < p.nc; ++c) total += kcnt[c];
+    if (total > (u32)GSORT_CAP) return;                 // uniform: nms_gather_kernel takes this image
+    if (tid == 0) {
+        p.out_counts[b] = (int)total;
+        u32 s = 0;
+        for (int c = 0; c < p.nc; ++c) { cpos[c] = s; s += kcnt[c]; }
+        cpos[p.nc] = s;
+    }
+    if (total == 0) return;
+    const u64 *kbase = p.kseg + b * p.A;
+    {
+        u32 pos = 0;
+        for (int c = 0; c < p.nc; ++c) {
+            const u32 m = kcnt[c];
+            const u64 *L = kbase + coff[c];
+            for (u32 j = tid; j < m; j += GATHER_THREADS) gk[pos + j] = L[j];
+            pos += m;
+        }
+    }
+    __syncthreads();
+    for (u32 e = tid; e < total; e += GATHER_THREADS) {
+        const u64 key = gk[e];
+        u32 rank = 0;
+        for (int c = 0; c < p.nc; ++c) {
+            const u32 lo0 = cpos[c], hi0 = cpos[c + 1];
+            if (lo0 == hi0) continue;
+            if (e >= lo0 && e < hi0) { rank += e - lo0; continue; }         // own list
+            u32 lo = lo0, hi = hi0;                                         // count of keys > key (descending list)
+            while (lo < hi) {
+                const u32 mid = (lo + hi) >> 1;
+                if (gk[mid] > key) lo = mid + 1; else hi = mid;
+            }
+            rank += lo - lo0;
+        }
+        p.bkey[b * p.A + rank] = key;                   // the bucket keys are dead after the sweep: kept keys in rank order
+    }
+}
+
+// Output rows of the images ranked by nms_gather_sort_kernel: 32 lanes per row, many workgroups per image so the
+// dependent source-row loads of different rows overlap.  Lane c loads column c of the source row, the first-maximum
+// class is reduced across the lanes, and lanes 0..W-1 write the output columns of row `rank`.
+constexpr int ROWS_PER_BLOCK = 32;
+__global__ __launch_bounds__(256) void nms_rows_kernel(NmsParams p)
+{
+    const long long b = blockIdx.y;
+    const u32 *kcnt = p.kcnt + b * p.nc;
+    if (p.nc > GSORT_MAXC) return;
+    u32 total = 0;
+    for (int c = 0; c < p.nc; ++c) total += kcnt[c];
+    if (total > (u32)GSORT_CAP) return;
+    const u32 nout = min(total, (u32)p.max_out);
+    const u32 rbase = blockIdx.x * ROWS_PER_BLOCK;
+    if (rbase >= nout) return;
+    const int tid = threadIdx.x;
+    const int sub = tid & 31, grp = tid >> 5;
+#pragma unroll
+    for (int it = 0; it < ROWS_PER_BLOCK / 8; ++it) {
+        const u32 r = rbase + it * 8 + grp;
+        const bool have = r < nout;                                    // uniform in the 32-lane group
+        const u64 key = p.bkey[b * p.A + (have ? r : rbase)];
+        const u32 idx = 0xFFFFFFFFu - (u32)key;
+        const float *row = p.pred + (b * p.A + idx) * (long long)p.C;
+        float *o = p.out_rows + (b * p.max_out + r) * (long long)p.W;
+        const float head = (sub < 5) ? row[sub] : 0.0f;
+        const float c0 = __shfl(head, 0, 32), c1 = __shfl(head, 1, 32), c2 = __shfl(head, 2, 32), c3 = __shfl(head, 3, 32);
+        const float obj = __shfl(head, 4, 32);
+        // first maximum over the classes: strided per lane, then across lanes (ties: smaller index); a NaN only
+        // wins as class 0, exactly like the sequential scan that starts from class 0
+        const float *cls0 = row + 5 + p.n_extra;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = sub; c < p.nc; c += 32) {
+            float v = cls0[c];
+            if (c > 0 && v != v) v = -INFINITY;
+            if (c == sub || v > bv) { bv = v; bi = c; }
+        }
+#pragma unroll
+        for (int m = 16; m > 0; m >>= 1) {
+            const float ov = __shfl_xor(bv, m, 32);
+            const int oi = __shfl_xor(bi, m, 32);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        bv = __shfl(bv, 0, 32);
+        bi = __shfl(bi, 0, 32);
+        float x1, y1, x2, y2;
+        if (p.in_cxcywh) {
+            const float hw = 0.5f * c2, hh = 0.5f * c3;
+            x1 = c0 - hw; y1 = c1 - hh; x2 = c0 + hw; y2 = c1 + hh;
+        } else {
+            x1 = c0; y1 = c1; x2 = c2; y2 = c3;
+        }
+        x1 = clamp_box(x1, p.hi); y1 = clamp_box(y1, p.hi); x2 = clamp_box(x2, p.hi); y2 = clamp_box(y2, p.hi);
+        if (!have) continue;
+        const float ov = sub == 0 ? x1 : (sub == 1 ? y1 : (sub == 2 ? x2 : (sub == 3 ? y2 : (sub == 4 ? obj : bv))));
+        if (sub < 6) o[sub] = ov;
+        for (int e = sub; e < p.n_extra; e += 32) o[6 + e] = row[5 + e];
+        if (sub == 6) o[p.W - 1] = (float)bi;
+        if (sub == 7 && p.out_index) p.out_index[b * p.max_out + r] = (int)idx;
     }
 }
 
@@ -660,6 +782,7 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     if (!attr_done) {
         YAMD_HIP(hipFuncSetAttribute((const void *)nms_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         YAMD_HIP(hipFuncSetAttribute((const void *)nms_segment_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        YAMD_HIP(hipFuncSetAttribute((const void *)nms_gather_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_done = true;
     }
     YAMD_HIP(hipMemsetAsync(ws + L.counters, 0, L.counters_bytes, st));
@@ -672,6 +795,13 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     YAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_segment_kernel, dim3(batch, nc), dim3(SEG_THREADS), slds, st, p);
     YAMD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_gather_sort_kernel, dim3(batch), dim3(GATHER_THREADS), (size_t)GSORT_CAP * sizeof(u64), st, p);
+    YAMD_LAUNCH_CHECK();
+    {
+        const int cap = max_out < GSORT_CAP ? max_out : GSORT_CAP;
+        hipLaunchKernelGGL(nms_rows_kernel, dim3(ceil_div(cap < a ? cap : a, ROWS_PER_BLOCK), batch), dim3(256), 0, st, p);
+        YAMD_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(nms_gather_kernel, dim3(batch, nc), dim3(GATHER_THREADS), 0, st, p);
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
