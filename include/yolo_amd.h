@@ -179,6 +179,19 @@ int yamd_nms_batched(const float *pred, int batch, int a, int c, int in_cxcywh, 
 int yamd_compact_rows(const float *rows, const int *counts, int batch, int max_out, int width, float *compact,
                       long long *offsets, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Inference pre-processing (the step in front of the path): transformer/transformer.py:134-178 ResizeImage
+ * (aspect-preserving PIL.Image.resize with BICUBIC, pasted centred on a (128,128,128) canvas) + :204-232 ImageNorm
+ * (/255, HWC -> CHW, float32).  img: (h, w, 3) uint8 RGB on the device, rows row_stride bytes apart;
+ * out: (3, target_h, target_w) float -- one image of the (B,3,S,S) batch the models take.  The resize follows
+ * Pillow's resampling bit for bit (separable, horizontal first, 22-bit fixed-point taps, uint8 between the passes).
+ * geom_host (4 ints: resize_w, resize_h, dw, dh) and ratio_host (resize_ratio) receive the bookkeeping RestoreSize
+ * (:260-295) needs; either may be NULL.
+ * ---------------------------------------------------------------------------------------- */
+size_t yamd_letterbox_workspace_bytes(int h, int w, int target_h, int target_w);
+int yamd_letterbox_u8(const uint8_t *img, int h, int w, int row_stride, int target_h, int target_w, float *out,
+                      int *geom_host, double *ratio_host, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -337,6 +337,45 @@ def gen_model(name):
         print(name, size, "keys", len(sd), "kept", counts.tolist(), "pred", tuple(pred.shape))
 
 
+def gen_preprocess():
+    """ResizeImage(is_train=False) + ImageNorm of the reference on random uint8 images (Pillow does the resize), and
+    RestoreSize on random boxes.  The reference's transformer module imports cv2/imgaug at the top (absent here), so
+    the three classes are loaded from its source with those two imports stubbed out."""
+    import importlib.util, types, PIL
+    from PIL import Image
+    for name in ("cv2", "imgaug", "imgaug.augmenters"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    spec = importlib.util.spec_from_file_location("ref_transformer", "/root/reference/luoyang/transformer/transformer.py")
+    T = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(T)
+    rng = np.random.RandomState(17)
+    out = {"pillow_version": np.array(PIL.__version__)}
+    cases = [(37, 53, 64, 64), (120, 90, 64, 64), (64, 64, 64, 64), (30, 100, 96, 96), (333, 500, 160, 160), (50, 40, 128, 96)]
+    for i, (h, w, th, tw) in enumerate(cases):
+        img = rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        # smooth half of the cases a little so that the fixtures are not pure noise
+        if i % 2:
+            img = np.array(Image.fromarray(img).resize((w, h), Image.BILINEAR).resize((w // 2 + 1, h // 2 + 1)).resize((w, h)))
+        d = {"image": Image.fromarray(img)}
+        T.ResizeImage(target_height=th, target_width=tw, is_train=False).transformer(d)
+        T.ImageNorm().transformer(d)
+        out[f"img{i}"] = img
+        out[f"out{i}"] = d["image"]
+        out[f"meta{i}"] = np.array([th, tw, d["ori_height"], d["ori_width"], d["resize_w"], d["resize_h"], d["dw"], d["dh"]],
+                                   np.int64)
+        out[f"ratio{i}"] = np.array(d["resize_ratio"], np.float64)
+        pred = np.concatenate((rng.uniform(-5, max(th, tw) + 5, (9, 4)), rng.uniform(0, 1, (9, 2)),
+                               rng.randint(0, 20, (9, 1))), 1).astype(np.float32)
+        d["predict"] = pred
+        T.RestoreSize().transformer(d)
+        out[f"pred{i}"] = pred
+        out[f"boxes{i}"] = np.asarray(d["predict_boxs"], np.int32)
+        out[f"labels{i}"] = np.asarray(d["predict_label"], np.int32)
+    out["n"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(GOLD, "preprocess.npz"), **out)
+    print("preprocess goldens:", len(cases), "cases, Pillow", PIL.__version__)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["nms", "decode", "v5s"]
@@ -346,6 +385,8 @@ if __name__ == "__main__":
         gen_decode()
     if "v5s" in which:
         gen_v5s()
+    if "preprocess" in which:
+        gen_preprocess()
     for name in _ref_models():
         if name in which:
             gen_model(name)

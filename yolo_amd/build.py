@@ -23,6 +23,7 @@ SOURCES = [
     ("yamd_conv_k3s2.hip", []),
     ("yamd_decode.hip", ["-ffp-contract=off"]),
     ("yamd_nms.hip", ["-ffp-contract=off"]),
+    ("yamd_preprocess.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
 HEADERS = [os.path.join(CSRC, "yamd_common.h"), os.path.join(CSRC, "yamd_conv_kernel.h"),
@@ -61,7 +62,7 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
         subprocess.check_call(cmd)
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(7, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs)
