@@ -180,3 +180,71 @@ def test_decode_ltrb_points_vs_oracle(gpu_device):
         got = tu.decode_ltrb_points([_nhwc(r, gpu_device) for r in raws], strides, P, nc, fmt).cpu().numpy()
         assert got.shape == want.shape
         np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+
+
+def _nms_case(gpu_device, pred, img, conf=0.1, thr=0.3):
+    from oracle import postprocess as pp
+    from yolo_amd import torch_utils as tu
+    want, want_idx = pp.non_max_suppression(pred, img, "cxcywh", conf, thr, return_index=True)
+    rows, counts, index = tu.nms_batched(torch.from_numpy(pred).to(gpu_device), img, "cxcywh", conf, thr, 0, want_index=True)
+    _check_rows(rows, counts, want, index, want_idx)
+    return counts.cpu().tolist()
+
+
+def _one_class_pred(box, score):
+    """(A,4) cxcywh boxes + (A,) objectness -> (1, A, 5+2) with every row in class 0"""
+    A = box.shape[0]
+    cls = np.concatenate((np.full((A, 1), 0.9), np.full((A, 1), 0.1)), -1)
+    return np.concatenate((box, score[:, None], cls), -1).astype(np.float32)[None]
+
+
+def test_nms_two_level_lattice_bucket(gpu_device):
+    """a bucket of 8000 boxes (two anchor planes of one class), sparse overlaps"""
+    rng = np.random.RandomState(3)
+    planes = []
+    for g, st, (aw, ah) in ((80, 8, (16, 30)), (40, 16, (30, 61))):
+        ys, xs = np.meshgrid(np.arange(g), np.arange(g), indexing="ij")
+        s = rng.uniform(0.6, 1.6, (g * g, 2))
+        planes.append(np.stack((xs.ravel() * st + st / 2 + rng.uniform(-2, 2, g * g), ys.ravel() * st + st / 2 + rng.uniform(-2, 2, g * g),
+                                aw * s[:, 0], ah * s[:, 1]), -1))
+    box = np.concatenate(planes, 0)
+    score = 0.5 + rng.uniform(-0.2, 0.2, box.shape[0])
+    kept = _nms_case(gpu_device, _one_class_pred(box, score), 640.0)
+    assert 1000 < kept[0] < 7000
+
+
+def test_nms_smooth_scores_long_dependency_chains(gpu_device):
+    """scores fall smoothly across the lattice: every decision depends on a long chain of earlier ones"""
+    g = 64
+    ys, xs = np.meshgrid(np.arange(g), np.arange(g), indexing="ij")
+    box = np.stack((xs.ravel() * 8 + 4.0, ys.ravel() * 8 + 4.0, np.full(g * g, 14.0), np.full(g * g, 14.0)), -1)
+    score = 0.9 - 0.5 * (xs.ravel() + 0.37 * ys.ravel()) / (1.37 * g)
+    _nms_case(gpu_device, _one_class_pred(box, score), 512.0)
+
+
+def test_nms_chain_of_3000(gpu_device):
+    """3000 boxes in a row, each overlapping only its neighbours, scores strictly falling: every other box survives"""
+    n = 3000
+    box = np.stack((np.arange(n) * 1.0 + 10.0, np.full(n, 50.0), np.full(n, 2.0), np.full(n, 20.0)), -1)
+    score = np.linspace(0.95, 0.2, n)
+    kept = _nms_case(gpu_device, _one_class_pred(box, score), 4096.0)
+    assert kept[0] == n // 2
+
+
+def test_nms_dense_cluster_in_sparse_background(gpu_device):
+    """700 near-identical boxes plus a sparse background in the same bucket"""
+    rng = np.random.RandomState(9)
+    dense = np.stack((100 + rng.uniform(-1, 1, 700), 100 + rng.uniform(-1, 1, 700), 40 + rng.uniform(-1, 1, 700),
+                      40 + rng.uniform(-1, 1, 700)), -1)
+    sparse = np.stack((rng.uniform(0, 640, 900), rng.uniform(0, 640, 900), rng.uniform(5, 40, 900), rng.uniform(5, 40, 900)), -1)
+    box = np.concatenate((dense, sparse), 0)
+    score = rng.uniform(0.2, 0.9, box.shape[0])
+    _nms_case(gpu_device, _one_class_pred(box, score), 640.0)
+
+
+def test_nms_bucket_larger_than_lds_sort_capacity(gpu_device):
+    rng = np.random.RandomState(11)
+    n = 9000
+    box = np.stack((rng.uniform(0, 640, n), rng.uniform(0, 640, n), rng.uniform(4, 30, n), rng.uniform(4, 30, n)), -1)
+    score = rng.uniform(0.2, 0.9, n)
+    _nms_case(gpu_device, _one_class_pred(box, score), 640.0)

@@ -180,6 +180,7 @@ __device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy
 
 constexpr int SEG_THREADS = 1024;           // 16 waves per bucket
 constexpr int SEG_WAVES = SEG_THREADS / 64;
+constexpr int CELLS = 4096;                 // grid cells of the spatial grouping
 
 // In-place bitonic sort, descending, of n (any n) 64-bit keys by one SEG_THREADS workgroup.  `a` may
 // point to LDS or to global memory.  The network only uses comparators that move the larger key to the
@@ -215,6 +216,82 @@ __device__ void bitonic_sort_desc(u64 *a, u32 n, int tid)
     }
 }
 
+// The same sort for keys that live in LDS, with the comparator network run three steps at a time: a thread loads the
+// 8 keys that three consecutive steps (partner distances 4s, 2s, s) connect, exchanges them in registers and stores
+// them back, so a 8192-key sort takes 33 passes over LDS (and barriers) instead of 91.  `a` must have room for the
+// next power of two of n keys; the tail is filled with zeros, which are smaller than every real key.
+__device__ __forceinline__ void cmpx(u64 &x, u64 &y, bool desc)
+{
+    const bool sw = desc ? (x < y) : (x > y);
+    const u64 t = x;
+    x = sw ? y : x;
+    y = sw ? t : y;
+}
+
+// Key i of an LDS-resident bucket lives in slot i + i/8: the spare slot after every 8 keys spreads the 64-byte runs
+// that one thread reads over all banks (2-way conflicts instead of 32-way).
+__device__ __forceinline__ u32 lds_slot(u32 i) { return i + (i >> 3); }
+
+__device__ void bitonic_sort_desc_blocked(u64 *a, u32 n, u32 npad, int tid)
+{
+    for (u32 i = n + tid; i < npad; i += SEG_THREADS) a[lds_slot(i)] = 0ull;
+    __syncthreads();
+    const u32 nthr = npad >> 3;
+    // levels k = 2, 4, 8 touch only aligned runs of 8 keys: one pass
+    if ((u32)tid < nthr) {
+        u64 v[8];
+        u64 *q = a + (size_t)tid * 9;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = q[m];
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) cmpx(v[m], v[m + 1], !(m & 2));                    // k=2
+#pragma unroll
+        for (int m = 0; m < 8; ++m) if (!(m & 2)) cmpx(v[m], v[m | 2], !(m & 4));         // k=4, j=2
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) cmpx(v[m], v[m + 1], !(m & 4));                    // k=4, j=1
+        const bool desc8 = !(tid & 1);                                                    // bit 3 of the key index 8*tid+m
+#pragma unroll
+        for (int m = 0; m < 4; ++m) cmpx(v[m], v[m | 4], desc8);                          // k=8, j=4
+#pragma unroll
+        for (int m = 0; m < 8; ++m) if (!(m & 2)) cmpx(v[m], v[m | 2], desc8);            // k=8, j=2
+#pragma unroll
+        for (int m = 0; m < 8; m += 2) cmpx(v[m], v[m + 1], desc8);                       // k=8, j=1
+#pragma unroll
+        for (int m = 0; m < 8; ++m) q[m] = v[m];
+    }
+    __syncthreads();
+    for (u32 k = 16; k <= npad; k <<= 1) {
+        u32 jh = k >> 1;
+        while (jh >= 1) {
+            const u32 sft = jh >= 4 ? (u32)(31 - __clz((int)jh)) - 2 : 0;       // log2(s)
+            const int a_top = jh >= 4 ? 2 : (jh == 2 ? 1 : 0);
+            const int nsteps = a_top + 1;
+            if ((u32)tid < nthr) {
+                const u32 blk = (u32)tid >> sft, r = (u32)tid & ((1u << sft) - 1u);
+                const u32 e0 = ((blk << 3) << sft) + r;
+                u64 v[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = a[lds_slot(e0 + ((u32)m << sft))];
+#pragma unroll
+                for (int st = 2; st >= 0; --st) {
+                    if (st > a_top) continue;
+                    const int dm = 1 << st;
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        if (m & dm) continue;
+                        const bool desc = !((e0 + ((u32)m << sft)) & k);
+                        cmpx(v[m], v[m | dm], desc);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < 8; ++m) a[lds_slot(e0 + ((u32)m << sft))] = v[m];
+            }
+            __syncthreads();
+            jh >>= nsteps;
+        }
+    }
+}
+
 __device__ __forceinline__ u32 spread10(u32 v)   // 10 bits -> every second bit
 {
     v &= 0x3ffu;
@@ -229,8 +306,9 @@ __device__ __forceinline__ float rl(float v, int lane) { return __uint_as_float(
 
 // One 16-wave workgroup per (class, image) bucket.
 //  1. sort the bucket's keys (descending = the stable descending score order),
-//  2. write keys / class-offset boxes in that order, then order the same boxes along a Morton curve of
-//     their centres so that 64 consecutive boxes form a spatially compact GROUP with a small bounding box,
+//  2. write keys / class-offset boxes in that order, then group the same boxes by place (counting sort into
+//     grid cells numbered along a Morton curve) so that 64 consecutive boxes form a compact GROUP with a small
+//     bounding box,
 //  3. greedy sweep in tiles of 64 score-consecutive boxes, two barriers per tile:
 //       B(t)  wave 0 resolves tile t serially on scalar bit masks from the tile's 64x64 suppression matrix
 //             (64 column ballots in LDS) and the removed-bits; the kept boxes go to LDS;
@@ -264,33 +342,130 @@ __global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
     const float coff = (float)cls * 4096.0f;
 
     // ---- 1. sort by key: in LDS when the bucket fits, else in place in global memory (skey)
-    const bool in_lds = n <= (u32)p.sort_cap;
+    u32 npad = 8;
+    while (npad < n) npad <<= 1;
+    const bool in_lds = npad <= (u32)p.sort_cap;
     u64 *S = in_lds ? (u64 *)smem_seg : skey;
-    for (u32 i = tid; i < n; i += SEG_THREADS) S[i] = keys[i];
+    for (u32 i = tid; i < n; i += SEG_THREADS) S[in_lds ? lds_slot(i) : i] = keys[i];
     __syncthreads();
-    bitonic_sort_desc(S, n, tid);
+    if (in_lds) bitonic_sort_desc_blocked(S, n, npad, tid);
+    else bitonic_sort_desc(S, n, tid);
 
-    // ---- 2. sorted keys + offset boxes out; Morton keys in
-    u64 *M = in_lds ? (u64 *)smem_seg : kseg;       // kseg is free until the sweep writes kept keys
+    // ---- 2. sorted keys + offset boxes out, then the same boxes grouped by place: a counting sort into the 4096
+    // cells of a 64x64 grid, cells numbered along a Morton curve, so that 64 consecutive boxes (a GROUP) lie close
+    // together.  The order inside a cell is whatever the tickets give; it only affects how tight the group bounding
+    // boxes are, never the result.  Buckets of at most one group skip the grouping.
     const float qs = 1024.0f / (p.hi + 1.0f);
-    for (u32 r = tid; r < n; r += SEG_THREADS) {
-        const u64 key = S[r];
-        const u32 idx = 0xFFFFFFFFu - (u32)key;
-        float x1, y1, x2, y2;
-        row_box(p.pred + (b * p.A + idx) * (long long)p.C, p.in_cxcywh, p.hi, x1, y1, x2, y2);
-        skey[r] = key;
-        sbox[r] = make_float4(x1 + coff, y1 + coff, x2 + coff, y2 + coff);
-        const u32 qx = (u32)fminf(fmaxf((x1 + x2) * 0.5f * qs, 0.0f), 1023.0f);
-        const u32 qy = (u32)fminf(fmaxf((y1 + y2) * 0.5f * qs, 0.0f), 1023.0f);
-        M[r] = ((u64)(spread10(qx) | (spread10(qy) << 1)) << 32) | (u64)r;
-    }
-    __syncthreads();
-    bitonic_sort_desc(M, n, tid);
-    for (u32 s = tid; s < n; s += SEG_THREADS) {
-        const u32 r = (u32)M[s];
-        mrank[s] = r;
-        posr[r] = s;
-        mbox[s] = sbox[r];
+    const bool grouped = n > 64u;
+    u32 *hist = (u32 *)smem_seg;                        // CELLS counters, then their exclusive prefix
+    u32 *wsum = hist + CELLS;                           // SEG_WAVES wave totals
+    auto cell_of = [&](float x1, float y1, float x2, float y2) __attribute__((always_inline)) {
+        const u32 qx = (u32)fminf(fmaxf((x1 + x2) * 0.5f * qs, 0.0f), 1023.0f) >> 4;
+        const u32 qy = (u32)fminf(fmaxf((y1 + y2) * 0.5f * qs, 0.0f), 1023.0f) >> 4;
+        return spread10(qx) | (spread10(qy) << 1);      // 12 bits
+    };
+    auto scan_cells = [&]() __attribute__((always_inline)) {
+        constexpr int PER = CELLS / SEG_THREADS;
+        u32 v[PER], sum = 0u;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { v[i] = hist[tid * PER + i]; sum += v[i]; }
+        u32 inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 o = (u32)__shfl_up((int)inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        u32 run = inc - sum;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { hist[tid * PER + i] = run; run += v[i]; }
+    };
+    if (in_lds) {
+        // at most RPT ranks per thread (r = tid + 1024 q): keys, boxes, cells and tickets stay in registers, and the
+        // scattered row reads of a thread are all in flight together
+        constexpr int RPT = 8192 / SEG_THREADS;
+        u64 kq[RPT];
+        float raw[RPT][4];
+        float4 ob[RPT];
+        u32 cq[RPT], tq[RPT];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const u32 r = tid + SEG_THREADS * q;
+            kq[q] = r < n ? S[lds_slot(r)] : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const u32 r = tid + SEG_THREADS * q;
+            if (r < n) {
+                const float *row = p.pred + (b * p.A + (0xFFFFFFFFu - (u32)kq[q])) * (long long)p.C;
+                raw[q][0] = row[0]; raw[q][1] = row[1]; raw[q][2] = row[2]; raw[q][3] = row[3];
+            } else {
+                raw[q][0] = raw[q][1] = raw[q][2] = raw[q][3] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const u32 r = tid + SEG_THREADS * q;
+            float x1, y1, x2, y2;
+            row_box(raw[q], p.in_cxcywh, p.hi, x1, y1, x2, y2);
+            ob[q] = make_float4(x1 + coff, y1 + coff, x2 + coff, y2 + coff);
+            cq[q] = cell_of(x1, y1, x2, y2);
+            if (r < n) {
+                skey[r] = kq[q];
+                sbox[r] = ob[q];
+                if (!grouped) { mrank[r] = r; posr[r] = r; mbox[r] = ob[q]; }
+            }
+        }
+        __syncthreads();                                // the sorted keys in LDS are dead from here
+        if (grouped) {
+            for (u32 c = tid; c < (u32)CELLS; c += SEG_THREADS) hist[c] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < RPT; ++q)
+                if (tid + SEG_THREADS * q < n) tq[q] = atomicAdd(&hist[cq[q]], 1u);
+            __syncthreads();
+            scan_cells();
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const u32 r = tid + SEG_THREADS * q;
+                if (r < n) {
+                    const u32 sp = hist[cq[q]] + tq[q];
+                    mrank[sp] = r;
+                    posr[r] = sp;
+                    mbox[sp] = ob[q];
+                }
+            }
+        }
+    } else {
+        // any bucket size: the keys were sorted in place in global memory; cells and tickets pass through posr
+        for (u32 r = tid; r < n; r += SEG_THREADS) {
+            const u64 key = S[r];
+            const u32 idx = 0xFFFFFFFFu - (u32)key;
+            float x1, y1, x2, y2;
+            row_box(p.pred + (b * p.A + idx) * (long long)p.C, p.in_cxcywh, p.hi, x1, y1, x2, y2);
+            sbox[r] = make_float4(x1 + coff, y1 + coff, x2 + coff, y2 + coff);
+            posr[r] = cell_of(x1, y1, x2, y2);
+        }
+        for (u32 c = tid; c < (u32)CELLS; c += SEG_THREADS) hist[c] = 0u;
+        __syncthreads();
+        for (u32 r = tid; r < n; r += SEG_THREADS) {
+            const u32 c = posr[r];
+            const u32 t = atomicAdd(&hist[c], 1u);
+            posr[r] = c | (t << 12);                    // ticket < n <= 65536
+        }
+        __syncthreads();
+        scan_cells();
+        __syncthreads();
+        for (u32 r = tid; r < n; r += SEG_THREADS) {
+            const u32 v = posr[r];
+            const u32 sp = hist[v & (u32)(CELLS - 1)] + (v >> 12);
+            mrank[sp] = r;
+            posr[r] = sp;
+            mbox[sp] = sbox[r];
+        }
     }
     __syncthreads();
     if (p.dbg & 1) { if (tid == 0) p.kcnt[b * p.nc + cls] = 0; return; }
@@ -739,12 +914,14 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     const size_t flds = (size_t)FROWS * (c | 1) * 4 + (size_t)nc * 8 + 16;
     YAMD_REQUIRE(flds <= 150 * 1024, "C=%d too wide for the filter tile", c);
     YAMD_REQUIRE(a <= 65536, "A=%d exceeds the 65536 anchors per image supported", a);
-    int sort_cap = 1;
+    int sort_cap = 8;
     while (sort_cap < a && sort_cap < 8192) sort_cap <<= 1;
     const size_t ngmax = (size_t)(a + 63) / 64;
     const size_t sweep_lds = ngmax * (16 + 8 + 4) + 64 * (16 + 8 + 4) + 16;
-    const size_t sort_lds = (size_t)sort_cap * 8;
-    const size_t slds = sort_lds > sweep_lds ? sort_lds : sweep_lds;
+    const size_t sort_lds = (size_t)sort_cap * 9;          // 8 bytes per key + one spare slot per 8 keys
+    size_t slds = sort_lds > sweep_lds ? sort_lds : sweep_lds;
+    const size_t group_lds = (size_t)(CELLS + SEG_WAVES) * 4;
+    if (slds < group_lds) slds = group_lds;
     char *ws = (char *)workspace;
     NmsParams p;
     p.pred = pred;
