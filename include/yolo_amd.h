@@ -192,6 +192,20 @@ size_t yamd_letterbox_workspace_bytes(int h, int w, int target_h, int target_w);
 int yamd_letterbox_u8(const uint8_t *img, int h, int w, int row_stride, int target_h, int target_w, float *out,
                       int *geom_host, double *ratio_host, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ----------------------------------------------------------------------------------------
+ * Detection metric: matching of ground truths to predictions.
+ * Replaces DetectMetric._get_batch_statistics (luoyang/model/metric/DetectMetric.py:35-105) with
+ * anchor_utils.bbox_iou (luoyang/utils/anchor_utils.py:25-44, the "+1" IoU) and x_y_w_h_to_x_y_x_y (:78-85).
+ * rows (batch, max_out, width) / counts (batch): the kept rows yamd_nms_batched wrote (class id in the last column).
+ * targets (batch, max_targets, 5) fp32 = normalised cx, cy, w, h, class id; all-zero rows are padding
+ * (DetectMetric.py:64); target_counts (batch) may be NULL (= max_targets rows each).
+ * true_positive (batch, max_out) uint8: 1 where a ground truth claimed the prediction with IoU >= iou_thr.
+ * Ground truths claim in stored order; ties in IoU go to the lower row; float32 arithmetic as numpy does it.
+ * ---------------------------------------------------------------------------------------- */
+int yamd_detect_match(const float *rows, const int *counts, int batch, int max_out, int width, const float *targets,
+                      const int *target_counts, int max_targets, float img_w, float img_h, float iou_thr,
+                      uint8_t *true_positive, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

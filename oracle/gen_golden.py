@@ -337,6 +337,72 @@ def gen_model(name):
         print(name, size, "keys", len(sd), "kept", counts.tolist(), "pred", tuple(pred.shape))
 
 
+def _metric_inputs(rng, B, img, nc, n_gt, n_fp):
+    """ground truths (normalised cx,cy,w,h,cls, zero-padded to a common length) and NMS-style prediction rows around them"""
+    preds, targets = [], []
+    for b in range(B):
+        g = int(rng.randint(0, n_gt + 1))
+        wh = rng.uniform(0.05, 0.4, (g, 2))
+        c = rng.uniform(0.2, 0.8, (g, 2))
+        cls = rng.randint(0, nc, (g, 1)).astype(np.float64)
+        t = np.concatenate((c, wh, cls), 1).astype(np.float32)
+        rows = []
+        for k in range(g):
+            for _ in range(int(rng.randint(0, 4))):                     # 0-3 detections per object, jittered
+                j = rng.normal(0, 0.02, 4)
+                x, y, w, h = (t[k, 0] + j[0]) * img, (t[k, 1] + j[1]) * img, (t[k, 2] + j[2]) * img, (t[k, 3] + j[3]) * img
+                lab = t[k, 4] if rng.uniform() < 0.85 else float(rng.randint(0, nc))
+                rows.append([x - w / 2, y - h / 2, x + w / 2, y + h / 2, rng.uniform(0.3, 1), rng.uniform(0.3, 1), lab])
+        for _ in range(int(rng.randint(0, n_fp + 1))):
+            x1, y1 = rng.uniform(0, img * 0.7, 2)
+            rows.append([x1, y1, x1 + rng.uniform(10, 150), y1 + rng.uniform(10, 150), rng.uniform(0.1, 0.6), rng.uniform(0.1, 0.9),
+                         float(rng.randint(0, nc))])
+        if rows and b % 5 == 0 and g:                                   # exact duplicates: IoU ties go to the first row
+            rows.append(list(rows[0]))
+        p = np.array(rows, np.float32).reshape(-1, 7)
+        if len(rows):
+            p = p[np.argsort(-(p[:, 4] * p[:, 5]), kind="stable")]
+        preds.append(p if len(rows) else None)
+        pad = np.zeros((n_gt, 5), np.float32)
+        pad[:g] = t
+        targets.append(pad if b % 7 != 3 else None)                      # some images carry no target tensor at all
+    return preds, targets
+
+
+def gen_metric():
+    """DetectMetric of the reference (metric_feed_forward over two batches, then summary) on synthetic detections."""
+    import importlib
+    DM = importlib.import_module("luoyang.model.metric.DetectMetric").DetectMetric
+    rng = np.random.RandomState(23)
+    out = {}
+    cases = [("voc20", 16, 640, 20, 12, 10, 0.5), ("few_classes", 8, 416, 3, 30, 40, 0.5), ("strict_iou", 8, 640, 5, 8, 5, 0.75)]
+    for name, B, img, nc, n_gt, n_fp, thr in cases:
+        names = [f"c{i}" for i in range(nc)]
+        m = DM(image_size=(img, img), class_names=names, predict_name="predicts", target_name="batch_targets", ap_iou_threshold=thr)
+        summary = {}
+        tps = []
+        for batch in range(2):
+            preds, targets = _metric_inputs(rng, B, img, nc, n_gt, n_fp)
+            for b in range(B):
+                out[f"{name}__b{batch}_pred{b}"] = np.zeros((0, 7), np.float32) if preds[b] is None else preds[b]
+                out[f"{name}__b{batch}_tgt{b}"] = np.zeros((0, 5), np.float32) if targets[b] is None else targets[b].copy()
+            out[f"{name}__b{batch}_pred_none"] = np.array([p is None for p in preds])
+            out[f"{name}__b{batch}_tgt_none"] = np.array([t is None for t in targets])
+            n0 = len(summary.get("sample_metrics", []))
+            m.metric_feed_forward({"predicts": preds, "batch_targets": [None if t is None else torch.from_numpy(t.copy()) for t in targets]},
+                                  summary)
+            new = summary["sample_metrics"][n0:]
+            out[f"{name}__b{batch}_tp"] = np.concatenate([x[0] for x in new]) if new else np.zeros(0)
+        res = m.summary(summary)
+        out[f"{name}__meta"] = np.array([B, img, nc, thr], np.float64)
+        out[f"{name}__mean"] = np.array([res["m_recall"], res["m_precision"], res["m_ap"]], np.float64)
+        out[f"{name}__per_class"] = np.array([[res[n]["precision"], res[n]["recall"], res[n]["f1_score"]] for n in names], np.float64)
+    out["cases"] = np.array([c[0] for c in cases])
+    out["numpy_version"] = np.array(np.__version__)
+    np.savez_compressed(os.path.join(GOLD, "metric.npz"), **out)
+    print("metric goldens:", [c[0] for c in cases], {k: out[k] for k in out if k.endswith("__mean")})
+
+
 def gen_preprocess():
     """ResizeImage(is_train=False) + ImageNorm of the reference on random uint8 images (Pillow does the resize), and
     RestoreSize on random boxes.  The reference's transformer module imports cv2/imgaug at the top (absent here), so
@@ -387,6 +453,8 @@ if __name__ == "__main__":
         gen_v5s()
     if "preprocess" in which:
         gen_preprocess()
+    if "metric" in which:
+        gen_metric()
     for name in _ref_models():
         if name in which:
             gen_model(name)
