@@ -102,6 +102,10 @@ int yamd_upsample2x(const void *x, int x_cstride, void *y, int y_cstride, int ba
  * (c % 8 == 0) and may live in the same concat buffer. h*w <= 1024. */
 int yamd_maxpool5_cascade(const void *x, int x_cstride, void *y1, void *y2, void *y3, int y_cstride,
                           int batch, int h, int w, int c, void *stream);
+/* The same with 3x3 pools: y1 = mp3(x), y2 = mp3(y1), y3 = mp3(y2), i.e. the k=3,5,7 pools of the face / pose
+ * SPPF (yolov5_face/Yolov5FaceBody.py:106-125). */
+int yamd_maxpool3_cascade(const void *x, int x_cstride, void *y1, void *y2, void *y3, int y_cstride,
+                          int batch, int h, int w, int c, void *stream);
 /* nn.MaxPool2d(kernel_size=2, stride=2) of the v7 transition blocks (yolov7_pose/YoloV7PoseBody.py:76-82):
  * x (batch,h,w,c) -> y (batch,h/2,w/2,c); h, w even, c % 8 == 0. */
 int yamd_maxpool2(const void *x, int x_cstride, void *y, int y_cstride, int batch, int h, int w, int c,

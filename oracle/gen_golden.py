@@ -274,7 +274,16 @@ def _ref_models():
         "v4": (YoloV4, lambda: Yolo4Param(), "desc", 7, 64),
         "v7pose": (YoloV7Pose, lambda: Yolo7PoseParam(m_type="l"), "desc", 6 + 3 * 17 + 1, 64),
         "v6face": (YoloV6Face, lambda: Yolo6FaceParam(m_type="s"), "v6", 6 + 2 * 5 + 1, 128),
+        "v5face": (_lazy("luoyang.yolov5_face.YoloV5Face", "YoloV5Face"), lambda: _lazy("luoyang.param.Param", "Yolo5FaceParam")(m_type="s"),
+                   "desc", 6 + 2 * 5 + 1, 64),
+        "v5pose": (_lazy("luoyang.yolov5_pose.YoloV5Pose", "YoloV5Pose"), lambda: _lazy("luoyang.param.Param", "Yolo5PoseParam")(m_type="s"),
+                   "desc", 6 + 3 * 17 + 1, 64),
     }
+
+
+def _lazy(module, attr):
+    import importlib
+    return getattr(importlib.import_module(module), attr)
 
 
 def _v6_raw_heads(model, imgs):

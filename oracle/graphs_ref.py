@@ -365,6 +365,16 @@ def model_ref(name: str):
                     decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "pose",
                                                                              point_num=p.point_num, clamp_points=predict),
                     nms=dict(in_fmt="cxcywh", point_num=17, point_conf=True))
+    if name == "v5face":
+        return dict(body=v5_ref.face_body_forward,
+                    decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "face",
+                                                                             point_num=p.point_num, clamp_points=predict),
+                    nms=dict(in_fmt="cxcywh", point_num=5, point_conf=False))
+    if name == "v5pose":
+        return dict(body=v5_ref.face_body_forward,
+                    decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "pose",
+                                                                             point_num=p.point_num, clamp_points=predict),
+                    nms=dict(in_fmt="cxcywh", point_num=17, point_conf=True))
     if name == "v6face":
         return dict(body=v6face_body,
                     decode=lambda raws, p, predict: decode_ref.decode_ltrb_points(raws, p.strides, p.point_num, p.class_num,

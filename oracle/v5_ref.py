@@ -44,9 +44,9 @@ def _c3(sd, p: str, x: torch.Tensor, shortcut: bool) -> torch.Tensor:
     return _conv_block(sd, p + ".cv3", torch.cat((a, b), 1))
 
 
-def _spp(sd, p: str, x: torch.Tensor) -> torch.Tensor:
+def _spp(sd, p: str, x: torch.Tensor, ks=(5, 9, 13)) -> torch.Tensor:
     x = _conv_block(sd, p + ".cv1", x)
-    pools = [F.max_pool2d(x, k, 1, k // 2) for k in (5, 9, 13)]
+    pools = [F.max_pool2d(x, k, 1, k // 2) for k in ks]
     return _conv_block(sd, p + ".cv2", torch.cat([x] + pools, 1))
 
 
@@ -85,3 +85,26 @@ def body_forward(sd: Dict[str, torch.Tensor], images: torch.Tensor, taps: Dict[s
     for name, t in (("yolo_head_P3", p3), ("yolo_head_P4", p4), ("yolo_head_P5", p5)):
         outs.append(F.conv2d(t, sd[n + name + ".weight"], sd[n + name + ".bias"]))
     return outs
+
+
+def face_body_forward(sd: Dict[str, torch.Tensor], images: torch.Tensor) -> List[torch.Tensor]:
+    """The v5 face / pose graph (luoyang/yolov5_face/Yolov5FaceBody.py: StemBlock :54-69, SPPF k=3,5,7 :106-125,
+    CSPDarknet :128-160, body forward :217-248; yolov5_pose/YoloV5PoseBody.py is the same graph)."""
+    bb = "body_net.backbone."
+    s1 = _conv_block(sd, bb + "stem.stem_1", images, 2)
+    s2 = _conv_block(sd, bb + "stem.stem_2b", _conv_block(sd, bb + "stem.stem_2a", s1), 2)
+    x = _conv_block(sd, bb + "stem.stem_3", torch.cat((s2, F.max_pool2d(s1, 2, 2, ceil_mode=True)), 1))
+    x = _c3(sd, bb + "dark2.0", x, True)
+    feat1 = _c3(sd, bb + "dark3.1", _conv_block(sd, bb + "dark3.0", x, 2), True)
+    feat2 = _c3(sd, bb + "dark4.1", _conv_block(sd, bb + "dark4.0", feat1, 2), True)
+    x = _spp(sd, bb + "dark5.1", _conv_block(sd, bb + "dark5.0", feat2, 2), (3, 5, 7))
+    feat3 = _c3(sd, bb + "dark5.2", x, False)
+    n = "body_net."
+    p5 = _conv_block(sd, n + "conv_for_feat3", feat3)
+    p4 = _c3(sd, n + "conv3_for_up_sample1", torch.cat((F.interpolate(p5, scale_factor=2, mode="nearest"), feat2), 1), False)
+    p4 = _conv_block(sd, n + "conv_for_feat2", p4)
+    p3 = _c3(sd, n + "conv3_for_up_sample2", torch.cat((F.interpolate(p4, scale_factor=2, mode="nearest"), feat1), 1), False)
+    p4 = _c3(sd, n + "conv3_for_down_sample1", torch.cat((_conv_block(sd, n + "down_sample1", p3, 2), p4), 1), False)
+    p5 = _c3(sd, n + "conv3_for_down_sample2", torch.cat((_conv_block(sd, n + "down_sample2", p4, 2), p5), 1), False)
+    return [F.conv2d(t, sd[n + name + ".weight"], sd[n + name + ".bias"])
+            for name, t in (("yolo_head_P3", p3), ("yolo_head_P4", p4), ("yolo_head_P5", p5))]

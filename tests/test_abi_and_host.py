@@ -123,7 +123,7 @@ def test_checkpoint_architecture_detection(tmp_path):
     import torch
     from yolo_amd import models
     from yolo_amd.init import seeded_state_dict
-    for name in ("v5s", "v8s", "v4", "v7pose", "v6face"):
+    for name in ("v5s", "v8s", "v4", "v7pose", "v6face", "v5face", "v5pose"):
         size = 128 if name == "v6face" else 64
         p, m = models.create(name, size)
         sd = seeded_state_dict(m, seed=2, mode="spread", **models.init_options(name))
@@ -133,7 +133,7 @@ def test_checkpoint_architecture_detection(tmp_path):
         assert type(m2) is type(m) and p2.class_num == p.class_num and p2.img_size == size
         assert getattr(p2, "m_type", None) == getattr(p, "m_type", None)
         assert list(m2.state_dict().keys()) == list(sd.keys())
-        if name in ("v4", "v7pose", "v6face"):
+        if name in ("v4", "v7pose", "v6face", "v5face"):
             m.load_state_dict(sd)
             m.fuse()
             p3, m3 = models.from_state_dict(m.state_dict(), size)

@@ -222,6 +222,15 @@ def test_upsample_copy_maxpool(gpu_device):
     for i, k in enumerate((5, 9, 13)):
         want = F.max_pool2d(s, k, 1, k // 2).permute(0, 2, 3, 1).to(torch.bfloat16)
         assert torch.equal(got[..., (i + 1) * c:(i + 2) * c], want), f"pool {k}"
+    # the 3x3 cascade: pools 3/5/7 of the face / pose SPPF
+    cd3 = cat.to(gpu_device)
+    p3 = cd3.data_ptr()
+    L.check(L.LIB.yamd_maxpool3_cascade(p3, 4 * c, p3 + c * 2, p3 + 2 * c * 2, p3 + 3 * c * 2, 4 * c, 3, H, W, c, st))
+    got = cd3.cpu()
+    assert torch.equal(got[..., :c], src)
+    for i, k in enumerate((3, 5, 7)):
+        want = F.max_pool2d(s, k, 1, k // 2).permute(0, 2, 3, 1).to(torch.bfloat16)
+        assert torch.equal(got[..., (i + 1) * c:(i + 2) * c], want), f"pool {k}"
 
 
 def test_maxpool2_and_conv_transpose(gpu_device):

@@ -1,10 +1,11 @@
-"""End to end on the GPU for every model family other than YOLOv5 (see test_gpu_v5_e2e.py): bf16 conv graph ->
+"""End to end on the GPU for every model family and variant other than YOLOv5 detect (see test_gpu_v5_e2e.py): bf16 conv graph ->
 fp32 decode -> NMS, against the reference's golden outputs (small size) and the CPU oracle graph (full size).
 
 bf16 tolerances (weights and activations rounded to bf16 through the whole conv chain, fp32 accumulate):
   raw head logits   relative L2 <= 3e-2 vs the fp32 reference
   decoded boxes     |d| <= 0.5 px + 1 % for all but 0.2 % of the values; scores |d| <= 2e-2 likewise
-                    (v3/v4 width/height: 0.5 px + 5 %, they are exp(logit) * anchor)
+                    (v3/v4 width/height: 0.5 px + 5 %, they are exp(logit) * anchor; v6 face and v5 face / pose:
+                    + 4 % of the row's stride resp. anchor size, see _row_stride)
 The kept set is compared by matching (same class, IoU > 0.9), because bf16 noise legitimately flips
 threshold decisions; NMS itself is bit-exact given identical input (test_gpu_postprocess.py).
 """
@@ -17,15 +18,24 @@ from test_gpu_v5_e2e import _check_pred, _match_rows, _rel_l2
 
 pytestmark = pytest.mark.gpu
 
-NAMES = ["v8s", "v3", "v4", "v7pose", "v6face"]
+NAMES = ["v8s", "v3", "v4", "v7pose", "v6face", "v5face", "v5pose"]
 EXP_WH = ("v3", "v4")
-POINTS = {"v7pose": 17, "v6face": 5}
+POINTS = {"v7pose": 17, "v6face": 5, "v5face": 5, "v5pose": 17}
 
 
 def _row_stride(name, p, size):
-    if name != "v6face":
-        return None
-    return np.concatenate([np.full((size // s) ** 2, s, np.float32) for s in p.strides])
+    """per-row length scale (pixels) by which the head multiplies a raw logit: the stride for the anchor-free v6 head,
+    the larger anchor side for the v5 face / pose heads (anchors up to 433 px; landmarks are logit x anchor, sizes
+    (2 sigmoid)^2 x anchor), whose random-init graph reaches the heads with a logit error of a few 1e-2"""
+    if name == "v6face":
+        return np.concatenate([np.full((size // s) ** 2, s, np.float32) for s in p.strides])
+    if name in ("v5face", "v5pose"):
+        out = []
+        for lvl, s in enumerate(p.strides):
+            for aw, ah in p.anchors[3 * lvl:3 * lvl + 3]:
+                out.append(np.full((size // s) ** 2, max(aw, ah), np.float32))
+        return np.concatenate(out)
+    return None
 
 
 def _match_rows_abs(got, want, tol):
@@ -117,7 +127,7 @@ def test_v8_feed_forward_keys(gpu_device):
     assert np.array_equal(boxes, pred[..., :4])
 
 
-@pytest.mark.parametrize("name", ["v4", "v7pose", "v6face"])
+@pytest.mark.parametrize("name", ["v4", "v7pose", "v6face", "v5face"])
 def test_fused_equals_unfused(name, gpu_device):
     """fuse() (BN folding, RepConv re-parameterisation) changes the checkpoint layout, not the outputs"""
     from yolo_amd.init import seeded_images
@@ -159,7 +169,8 @@ def test_yolo_predict_entry_points(gpu_device, tmp_path):
         assert (a is None and b is None) or np.array_equal(a, b.cpu().numpy())
 
 
-FULL = {"v8s": 128, "v3": 256, "v4": 256, "v7pose": 512, "v6face": 512}     # BASELINE per-GPU batch sizes
+FULL = {"v8s": 128, "v3": 256, "v4": 256, "v7pose": 512, "v6face": 512,     # BASELINE per-GPU batch sizes
+        "v5face": 256, "v5pose": 256}                                         # (variants: the v5s batch)
 
 
 @pytest.mark.parametrize("name", NAMES)

@@ -154,8 +154,9 @@ __global__ void maxpool2_kernel(const __bf16 *__restrict__ x, int x_cs, __bf16 *
 }
 
 // One workgroup per (image, 8-channel piece): the whole h*w plane of 16-byte pixels sits in LDS;
-// a 5x5 max is a 5-tap row pass followed by a 5-tap column pass, applied three times.
-__global__ void maxpool5_cascade_kernel(const __bf16 *__restrict__ x, int x_cs, __bf16 *__restrict__ y1,
+// a (2R+1)x(2R+1) max is a row pass followed by a column pass, applied three times (R = 2: 5x5, R = 1: 3x3).
+template <int R>
+__global__ void maxpool_cascade_kernel(const __bf16 *__restrict__ x, int x_cs, __bf16 *__restrict__ y1,
                                         __bf16 *__restrict__ y2, __bf16 *__restrict__ y3, int y_cs, int H, int W, int C8)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -172,7 +173,7 @@ __global__ void maxpool5_cascade_kernel(const __bf16 *__restrict__ x, int x_cs, 
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int r = i / W, c = i % W;
             bf16x8 m = cur[i];
-            for (int d = -2; d <= 2; ++d) {
+            for (int d = -R; d <= R; ++d) {
                 const int cc = c + d;
                 if (d != 0 && cc >= 0 && cc < W) m = max8(m, cur[r * W + cc]);
             }
@@ -182,7 +183,7 @@ __global__ void maxpool5_cascade_kernel(const __bf16 *__restrict__ x, int x_cs, 
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const int r = i / W, c = i % W;
             bf16x8 m = tmp[i];
-            for (int d = -2; d <= 2; ++d) {
+            for (int d = -R; d <= R; ++d) {
                 const int rr = r + d;
                 if (d != 0 && rr >= 0 && rr < H) m = max8(m, tmp[rr * W + c]);
             }
@@ -280,8 +281,9 @@ extern "C" int yamd_maxpool2(const void *x, int x_cstride, void *y, int y_cstrid
     return YAMD_OK;
 }
 
-extern "C" int yamd_maxpool5_cascade(const void *x, int x_cstride, void *y1, void *y2, void *y3, int y_cstride, int batch,
-                                     int h, int w, int c, void *stream)
+namespace {
+int maxpool_cascade(int radius, const void *x, int x_cstride, void *y1, void *y2, void *y3, int y_cstride, int batch, int h, int w,
+                    int c, void *stream)
 {
     YAMD_REQUIRE(x && y1 && y2 && y3, "null argument");
     YAMD_REQUIRE(batch > 0 && h > 0 && w > 0 && h * w <= 1024 && c > 0 && c % 8 == 0, "maxpool: bad shape %dx%dx%d", h, w, c);
@@ -289,8 +291,22 @@ extern "C" int yamd_maxpool5_cascade(const void *x, int x_cstride, void *y1, voi
                      ((uintptr_t)y2 % 16) == 0 && ((uintptr_t)y3 % 16) == 0,
                  "maxpool needs 16-byte aligned pixels");
     const size_t lds = (size_t)h * w * 16 * 2;
-    hipLaunchKernelGGL(maxpool5_cascade_kernel, dim3(batch * (c / 8)), dim3(256), lds, (hipStream_t)stream,
-                       (const __bf16 *)x, x_cstride, (__bf16 *)y1, (__bf16 *)y2, (__bf16 *)y3, y_cstride, h, w, c / 8);
+    auto kern = radius == 2 ? maxpool_cascade_kernel<2> : maxpool_cascade_kernel<1>;
+    hipLaunchKernelGGL(kern, dim3(batch * (c / 8)), dim3(256), lds, (hipStream_t)stream, (const __bf16 *)x, x_cstride,
+                       (__bf16 *)y1, (__bf16 *)y2, (__bf16 *)y3, y_cstride, h, w, c / 8);
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
+}
+}  // namespace
+
+extern "C" int yamd_maxpool5_cascade(const void *x, int x_cstride, void *y1, void *y2, void *y3, int y_cstride, int batch,
+                                     int h, int w, int c, void *stream)
+{
+    return maxpool_cascade(2, x, x_cstride, y1, y2, y3, y_cstride, batch, h, w, c, stream);
+}
+
+extern "C" int yamd_maxpool3_cascade(const void *x, int x_cstride, void *y1, void *y2, void *y3, int y_cstride, int batch,
+                                     int h, int w, int c, void *stream)
+{
+    return maxpool_cascade(1, x, x_cstride, y1, y2, y3, y_cstride, batch, h, w, c, stream);
 }

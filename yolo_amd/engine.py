@@ -126,10 +126,12 @@ class Program:
         self.ops.append(("up2", x, out))
         return out
 
-    def maxpool5_cascade(self, x: View, y1: View, y2: View, y3: View) -> None:
+    def maxpool5_cascade(self, x: View, y1: View, y2: View, y3: View, kernel: int = 5) -> None:
+        """y1 = mp(x), y2 = mp(y1), y3 = mp(y2) with kernel x kernel stride-1 pools (5: SPP k 5/9/13; 3: k 3/5/7)."""
+        assert kernel in (3, 5)
         for y in (y1, y2, y3):
             assert (y.h, y.w, y.c) == (x.h, x.w, x.c) and y.buf == y1.buf
-        self.ops.append(("mp5", x, y1, y2, y3))
+        self.ops.append(("mp5", x, y1, y2, y3, kernel))
 
     def copy(self, x: View, out: View) -> View:
         assert (out.h, out.w, out.c) == (x.h, x.w, x.c)
@@ -339,12 +341,13 @@ class Program:
                 yp, ycs = P(bufs, out)
                 _lib.check(LIB.yamd_upsample2x(xp, xcs, yp, ycs, B, x.h, x.w, x.c, st), "upsample2x")
             elif kind == "mp5":
-                _, x, y1, y2, y3 = op
+                _, x, y1, y2, y3, kernel = op
                 xp, xcs = P(bufs, x)
                 p1, ycs = P(bufs, y1)
                 p2, _ = P(bufs, y2)
                 p3, _ = P(bufs, y3)
-                _lib.check(LIB.yamd_maxpool5_cascade(xp, xcs, p1, p2, p3, ycs, B, x.h, x.w, x.c, st), "maxpool5")
+                fn = LIB.yamd_maxpool5_cascade if kernel == 5 else LIB.yamd_maxpool3_cascade
+                _lib.check(fn(xp, xcs, p1, p2, p3, ycs, B, x.h, x.w, x.c, st), "maxpool_cascade")
             elif kind == "copy":
                 _, x, out = op
                 xp, xcs = P(bufs, x)

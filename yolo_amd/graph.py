@@ -125,6 +125,7 @@ class AnchorTaskModel(TaskModel):
     DECODE_KIND = _lib.DECODE_V5
     POINT_NUM = 0            # keypoints / landmarks per box
     POINT_CONF = False       # True: one confidence column per keypoint (pose)
+    CLAMP_POINTS_IN_PREDICT = None   # None: as POINT_CONF (pose clamps keypoints in predict, v7 face does not)
 
     def raw_heads(self, images: torch.Tensor) -> List[torch.Tensor]:
         """Raw head logits [P3, P4, P5], float32 NHWC (B,h,w,3*C)."""
@@ -161,7 +162,8 @@ class AnchorTaskModel(TaskModel):
         return (3 if self.POINT_CONF else 2) * self.POINT_NUM
 
     def decode_predict(self, raws) -> torch.Tensor:
-        return self._merge(raws, self.POINT_NUM > 0 and self.POINT_CONF)
+        clamp = self.POINT_CONF if self.CLAMP_POINTS_IN_PREDICT is None else self.CLAMP_POINTS_IN_PREDICT
+        return self._merge(raws, self.POINT_NUM > 0 and clamp)
 
     def nms_predict(self, pred: torch.Tensor):
         rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "cxcywh", self.param.conf_threshold,

@@ -9,10 +9,15 @@ def registry() -> Dict[str, Dict[str, Any]]:
     from .yolov3 import YoloV3
     from .yolov4 import YoloV4
     from .yolov5 import YoloV5
+    from .yolov5_face import YoloV5Face, YoloV5Pose
     from .yolov6_face import YoloV6Face
     from .yolov7_pose import YoloV7Pose
     from .yolov8 import YoloV8
     return {
+        # at 640x640 the random-init features of this graph reach the heads with a std near 10: damp the head convs
+        # so that the logits stay in the range of a trained network
+        "v5face": dict(cls=YoloV5Face, param=lambda: _param.Yolo5FaceParam(m_type="s"), init=dict(scale={"yolo_head_P": 0.1})),
+        "v5pose": dict(cls=YoloV5Pose, param=lambda: _param.Yolo5PoseParam(m_type="s"), init=dict(scale={"yolo_head_P": 0.1})),
         "v5s": dict(cls=YoloV5, param=lambda: _param.Yolo5Param(m_type="s").set_img_size(640), init={}),
         "v8s": dict(cls=YoloV8, param=lambda: _param.Yolo8Param(m_type="s"), init={}),
         # 23 un-normalised residual adds: damp the branch output so random-init activations stay in range, and the
@@ -78,6 +83,18 @@ def from_state_dict(sd, img_size: int, output_size: int = 0, point_num: int = 0)
     elif has("body_net.backbone.stages.0.downsample_conv.conv.weight"):
         nc = sd["body_net.yolo_head3.1.weight"].shape[0] // 3 - 5
         p, cls = with_classes(_param.Yolo4Param(), nc), YoloV4
+    elif has("body_net.backbone.stem.stem_1.conv.weight"):
+        # v5 face / pose share one graph; the head width tells them apart: 5 + 3*17 + classes (pose, one confidence
+        # per keypoint) when that leaves at least one class, else 5 + 2*points + classes (face)
+        from .yolov5_face import YoloV5Face, YoloV5Pose
+        t = width_type(sd["body_net.backbone.stem.stem_1.conv.weight"].shape[0], {"s": 32, "m": 48, "l": 64, "x": 80})
+        oc = sd["body_net.yolo_head_P3.weight"].shape[0] // 3
+        if point_num in (0, 17) and oc - 5 - 3 * 17 >= 1:
+            p, cls = with_classes(_param.Yolo5PoseParam(m_type=t), oc - 5 - 3 * 17), YoloV5Pose
+        else:
+            p = _param.Yolo5FaceParam(m_type=t)
+            p.point_num = point_num or p.point_num
+            p, cls = with_classes(p, oc - 5 - 2 * p.point_num), YoloV5Face
     elif has("body_net.backbone.stem.conv.conv.weight"):
         t = width_type(sd["body_net.backbone.stem.conv.conv.weight"].shape[0], {"s": 32, "m": 48, "l": 64, "x": 80})
         nc = sd["body_net.yolo_head_P3.weight"].shape[0] // 3 - 5
