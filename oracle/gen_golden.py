@@ -274,6 +274,9 @@ def _ref_models():
         "v4": (YoloV4, lambda: Yolo4Param(), "desc", 7, 64),
         "v7pose": (YoloV7Pose, lambda: Yolo7PoseParam(m_type="l"), "desc", 6 + 3 * 17 + 1, 64),
         "v6face": (YoloV6Face, lambda: Yolo6FaceParam(m_type="s"), "v6", 6 + 2 * 5 + 1, 128),
+        "v7": (_lazy("luoyang.yolov7.YoloV7", "YoloV7"), lambda: _lazy("luoyang.param.Param", "Yolo7Param")(m_type="l"), "desc", 7, 64),
+        "v7face": (_lazy("luoyang.yolov7_face.YoloV7Face", "YoloV7Face"), lambda: _lazy("luoyang.param.Param", "Yolo7FaceParam")(m_type="l"),
+                   "desc", 6 + 2 * 5 + 1, 64),
         "v5face": (_lazy("luoyang.yolov5_face.YoloV5Face", "YoloV5Face"), lambda: _lazy("luoyang.param.Param", "Yolo5FaceParam")(m_type="s"),
                    "desc", 6 + 2 * 5 + 1, 64),
         "v5pose": (_lazy("luoyang.yolov5_pose.YoloV5Pose", "YoloV5Pose"), lambda: _lazy("luoyang.param.Param", "Yolo5PoseParam")(m_type="s"),
@@ -325,7 +328,22 @@ def gen_model(name):
             if order == "desc":
                 raws = raws[::-1]
             pred = model._forward(imgs)[0]
-            res = model.predict({"batch_images": imgs})["predicts"]
+            try:
+                res = model.predict({"batch_images": imgs})["predicts"]
+            except AttributeError as e:
+                # luoyang/yolov7_face/YoloV7Face.py defines `_forward` twice (:58, :71) and no `_feed_forward`, so its
+                # predict() (:130-166) cannot run.  Its remaining lines are applied by hand to the `_forward` tensor
+                # (boxes already scaled and clamped there): landmark clamp :153-156, then the reference's own
+                # torch_utils.non_max_suppression_with_point :157-161.
+                print(name, "reference predict() unavailable:", repr(e))
+                import luoyang.utils.torch_utils as ref_tu
+                q = pred.clone()
+                k1 = 5 + 2 * p.point_num
+                q[..., 5:k1] = torch.clamp(q[..., 5:k1], min=0, max=p.img_size - 1)
+                res = [None if r is None else r.numpy()
+                       for r in ref_tu.non_max_suppression_with_point(prediction=q, point_num=p.point_num,
+                                                                      conf_threshold=p.conf_threshold,
+                                                                      nms_threshold=p.nms_threshold, img_size=p.img_size)]
         counts, rows = _rows(res, width)
         d = dict(seed=seed, size=size, batch=batch, counts=counts, rows=rows, n_keys=len(sd),
                  conf_threshold=p.conf_threshold, nms_threshold=p.nms_threshold)

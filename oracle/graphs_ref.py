@@ -365,6 +365,15 @@ def model_ref(name: str):
                     decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "pose",
                                                                              point_num=p.point_num, clamp_points=predict),
                     nms=dict(in_fmt="cxcywh", point_num=17, point_conf=True))
+    if name == "v7":
+        return dict(body=v7pose_body,
+                    decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "v5"),
+                    nms=dict(in_fmt="cxcywh"))
+    if name == "v7face":
+        return dict(body=v7pose_body,
+                    decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "face",
+                                                                             point_num=p.point_num, clamp_points=predict),
+                    nms=dict(in_fmt="cxcywh", point_num=5, point_conf=False))
     if name == "v5face":
         return dict(body=v5_ref.face_body_forward,
                     decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "face",

@@ -123,7 +123,7 @@ def test_checkpoint_architecture_detection(tmp_path):
     import torch
     from yolo_amd import models
     from yolo_amd.init import seeded_state_dict
-    for name in ("v5s", "v8s", "v4", "v7pose", "v6face", "v5face", "v5pose"):
+    for name in ("v5s", "v8s", "v4", "v7pose", "v6face", "v5face", "v5pose", "v7", "v7face"):
         size = 128 if name == "v6face" else 64
         p, m = models.create(name, size)
         sd = seeded_state_dict(m, seed=2, mode="spread", **models.init_options(name))

@@ -125,7 +125,7 @@ class AnchorTaskModel(TaskModel):
     DECODE_KIND = _lib.DECODE_V5
     POINT_NUM = 0            # keypoints / landmarks per box
     POINT_CONF = False       # True: one confidence column per keypoint (pose)
-    CLAMP_POINTS_IN_PREDICT = None   # None: as POINT_CONF (pose clamps keypoints in predict, v7 face does not)
+    CLAMP_POINTS_IN_PREDICT = None   # None: as POINT_CONF; the face models set True (their predict() clamps landmarks too)
 
     def raw_heads(self, images: torch.Tensor) -> List[torch.Tensor]:
         """Raw head logits [P3, P4, P5], float32 NHWC (B,h,w,3*C)."""

@@ -11,6 +11,7 @@ def registry() -> Dict[str, Dict[str, Any]]:
     from .yolov5 import YoloV5
     from .yolov5_face import YoloV5Face, YoloV5Pose
     from .yolov6_face import YoloV6Face
+    from .yolov7 import YoloV7, YoloV7Face
     from .yolov7_pose import YoloV7Pose
     from .yolov8 import YoloV8
     return {
@@ -28,6 +29,8 @@ def registry() -> Dict[str, Dict[str, Any]]:
                    init=dict(scale={".block.1.conv.weight": 0.25, "yolo_head1.1.weight": 0.05,
                                     "yolo_head2.1.weight": 0.05, "yolo_head3.1.weight": 0.05})),
         "v7pose": dict(cls=YoloV7Pose, param=lambda: _param.Yolo7PoseParam(m_type="l"), init={}),
+        "v7": dict(cls=YoloV7, param=lambda: _param.Yolo7Param(m_type="l"), init={}),
+        "v7face": dict(cls=YoloV7Face, param=lambda: _param.Yolo7FaceParam(m_type="l"), init={}),
         # RepVGG blocks sum three un-normalised branches ~40 times in a row: scale the branch BatchNorms so that the
         # sum keeps the activation variance; box/landmark logits (grid units, multiplied by the stride) get a std near 1
         "v6face": dict(cls=YoloV6Face, param=lambda: _param.Yolo6FaceParam(m_type="s"),
@@ -106,12 +109,21 @@ def from_state_dict(sd, img_size: int, output_size: int = 0, point_num: int = 0)
         nc = sd["body_net.cv3.0.2.weight"].shape[0]
         p, cls = with_classes(_param.Yolo8Param(m_type=t), nc), YoloV8
     elif has("body_net.backbone.stem.0.conv.weight") or has("body_net.backbone.stem.0.conv.bias"):
+        # the three v7 models share one graph; the head width (and the caller's point count) tells them apart:
+        # pose 5 + 3 x 17 + classes, face 5 + 2 x 5 + classes, detect 5 + classes
+        from .yolov7 import YoloV7, YoloV7Face
         t = width_type(sd["body_net.backbone.stem.0.conv.weight"].shape[0], {"l": 32, "x": 40})
-        p = _param.Yolo7PoseParam(m_type=t)
-        if point_num:
-            p.point_num = point_num
-        nc = sd["body_net.yolo_head_P3.weight"].shape[0] // 3 - 5 - 3 * p.point_num
-        p, cls = with_classes(p, nc), YoloV7Pose
+        oc = sd["body_net.yolo_head_P3.weight"].shape[0] // 3
+        if point_num >= 10 or (point_num == 0 and oc - 5 - 3 * 17 >= 1):
+            p = _param.Yolo7PoseParam(m_type=t)
+            p.point_num = point_num or p.point_num
+            p, cls = with_classes(p, oc - 5 - 3 * p.point_num), YoloV7Pose
+        elif point_num > 0 or oc == 16:
+            p = _param.Yolo7FaceParam(m_type=t)
+            p.point_num = point_num or p.point_num
+            p, cls = with_classes(p, oc - 5 - 2 * p.point_num), YoloV7Face
+        else:
+            p, cls = with_classes(_param.Yolo7Param(m_type=t), oc - 5), YoloV7
     elif any(k.startswith("yolo_body.back_bone_network.stem.") for k in keys):
         k = "yolo_body.head.stems.0.block.conv.weight"
         t = width_type(sd[k].shape[0], {"n": 32, "s": 64})

@@ -74,7 +74,7 @@ def rep_conv_equivalent(m: nn.Module):
     return w, b
 
 
-def _tree(param: Yolo7PoseParam, anchor_num: int) -> nn.Module:
+def _tree(param, anchor_num: int, cols: int) -> nn.Module:
     phi = param.m_type
     tc = {"l": 32, "x": 40}[phi]
     bc = 32
@@ -104,7 +104,7 @@ def _tree(param: Yolo7PoseParam, anchor_num: int) -> nn.Module:
     body.conv3_for_down_sample2 = _mcb(tc * 32, pc * 8, tc * 16, n, e, nids)
     mk = rep_conv if phi == "l" else (lambda a, b: conv_bn(a, b, 3, 1))
     body.rep_conv_1, body.rep_conv_2, body.rep_conv_3 = mk(tc * 4, tc * 8), mk(tc * 8, tc * 16), mk(tc * 16, tc * 32)
-    out = anchor_num * (5 + param.point_num * 3 + param.class_num)
+    out = anchor_num * cols        # per-anchor columns: 5 + classes (+ 2 or 3 per keypoint)
     body.yolo_head_P3 = nn.Conv2d(tc * 8, out, 1)
     body.yolo_head_P4 = nn.Conv2d(tc * 16, out, 1)
     body.yolo_head_P5 = nn.Conv2d(tc * 32, out, 1)
@@ -123,7 +123,7 @@ class YoloV7Pose(AnchorTaskModel):
         self.param = param
         self.POINT_NUM = param.point_num
         self.body_output_size = 5 + 3 * param.point_num + param.class_num
-        self.body_net = _tree(param, anchor_num)
+        self.body_net = _tree(param, anchor_num, self.body_output_size)
         self.eval()
 
     # ---- graph -----------------------------------------------------------------------------------
