@@ -276,15 +276,32 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_kernel(Co
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            for (int r = 0; r < 32; ++r) {
-                const int pq = wave * (32 * MREP) + m * 32 + r;
-                const int qr = pq / TW, qc = pq % TW;
-                if (!(qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)) continue;      // uniform in the wave
-                float *y = (float *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + nt * (NREP * 32);
-                const int nco = min(NREP * 32, p.Cout - nt * (NREP * 32));
+            const int nco = min(NREP * 32, p.Cout - nt * (NREP * 32));
+            if (p.n_tiles == 1 && p.y_cs == p.Cout) {
+                // pixels are dense in memory (one cout tile, no channel slice): walk the 32 x Cout values of the
+                // fragment as one flat run, so every store instruction writes 256 contiguous bytes across pixel
+                // boundaries (neighbouring pixels of a tile row are neighbours in memory)
+                const float inv = 1.0f / (float)nco;
+                const int total = 32 * nco;
+                for (int i = lane; i < total; i += 64) {
+                    const int r = (int)(((float)i + 0.5f) * inv);
+                    const int c = i - r * nco;
+                    const int pq = wave * (32 * MREP) + m * 32 + r;
+                    const int qr = pq / TW, qc = pq % TW;
+                    if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)
+                        ((float *)p.y)[((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + c] =
+                            *(const float *)(wreg + r * RSF + c * 4);
+                }
+            } else {
+                for (int r = 0; r < 32; ++r) {
+                    const int pq = wave * (32 * MREP) + m * 32 + r;
+                    const int qr = pq / TW, qc = pq % TW;
+                    if (!(qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)) continue;      // uniform in the wave
+                    float *y = (float *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + nt * (NREP * 32);
 #pragma unroll
-                for (int c = lane; c < NREP * 32; c += 64)
-                    if (c < nco) y[c] = *(const float *)(wreg + r * RSF + c * 4);
+                    for (int c = lane; c < NREP * 32; c += 64)
+                        if (c < nco) y[c] = *(const float *)(wreg + r * RSF + c * 4);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
