@@ -81,6 +81,13 @@ int yamd_conv_pack_weights(const yamd_conv_desc *d, const float *w_oihw_host, in
 int yamd_conv2d_bias_act(const yamd_conv_desc *d, const void *x, int x_cstride, const void *w_packed,
                          const float *bias_packed, const void *residual, int res_cstride, void *y,
                          int y_cstride, int batch, int h, int w, void *stream);
+/* The same conv with its output channels going to two places: couts [0, split_cout) to y, couts [split_cout, cout) to
+ * y2 (at channel cout - split_cout).  Used where one conv computes two branches that read the same input (C3's cv1 and
+ * cv2, yolov5/YoloV5Body.py:96-111) and their consumers should find each branch densely packed.  bf16 output, no
+ * residual; split_cout % 8 == 0. */
+int yamd_conv2d_bias_act_split(const yamd_conv_desc *d, const void *x, int x_cstride, const void *w_packed,
+                               const float *bias_packed, void *y, int y_cstride, void *y2, int y2_cstride,
+                               int split_cout, int batch, int h, int w, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Layout / resampling helpers of the conv graph.

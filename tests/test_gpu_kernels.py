@@ -265,3 +265,39 @@ def test_maxpool2_and_conv_transpose(gpu_device):
     assert got.shape == want.shape
     rel = torch.linalg.norm(got - want) / torch.linalg.norm(want)
     assert rel <= 1e-2, float(rel)
+
+
+@pytest.mark.parametrize("k,s,cin,cout,split,H,W", [(1, 1, 64, 64, 32, 40, 40), (1, 1, 32, 128, 96, 17, 23), (3, 1, 32, 64, 8, 20, 20),
+                                                    (3, 2, 64, 128, 64, 32, 32)])
+def test_conv_split_output(gpu_device, k, s, cin, cout, split, H, W):
+    """yamd_conv2d_bias_act_split: couts [0, split) land in one channel slice, the rest densely in a second buffer;
+    values are those of the plain conv, bit for bit, and nothing outside the two targets is written"""
+    from yolo_amd import lib as L
+    g = torch.Generator().manual_seed(cin + cout + split)
+    Bn = 2
+    x = _bf16_round(torch.randn((Bn, cin, H, W), generator=g))
+    w = _bf16_round(torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+    b = torch.randn((cout,), generator=g) * 0.5
+    want = _run_conv(gpu_device, x, w, b, k, s, 1)
+    d = L.ConvDesc()
+    L.check(L.LIB.yamd_conv_desc_init(ctypes.byref(d), k, s, cin, cout, 1, 0))
+    wp = torch.empty(d.packed_w_elems, dtype=torch.int16)
+    bp = torch.empty(d.cout_pad, dtype=torch.float32)
+    L.check(L.LIB.yamd_conv_pack_weights(ctypes.byref(d), w.contiguous().data_ptr(), cin, b.contiguous().data_ptr(), wp.data_ptr(),
+                                         bp.data_ptr()))
+    xin = x.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous().to(gpu_device)
+    Ho, Wo = want.shape[2], want.shape[3]
+    y1 = torch.full((Bn, Ho, Wo, split + 16), -3.0, dtype=torch.bfloat16, device=gpu_device)      # slice [8, 8+split)
+    y2 = torch.full((Bn, Ho, Wo, cout - split + 8), -5.0, dtype=torch.bfloat16, device=gpu_device)  # slice [0, cout-split)
+    wd, bd = wp.to(gpu_device), bp.to(gpu_device)
+    L.check(L.LIB.yamd_conv2d_bias_act_split(ctypes.byref(d), xin.data_ptr(), cin, wd.data_ptr(), bd.data_ptr(),
+                                             y1.data_ptr() + 8 * 2, y1.shape[-1], y2.data_ptr(), y2.shape[-1], split, Bn, H, W,
+                                             L.current_stream()), "conv split")
+    torch.cuda.synchronize()
+    a, c = y1.cpu().float(), y2.cpu().float()
+    assert torch.all(a[..., :8] == -3.0) and torch.all(a[..., 8 + split:] == -3.0) and torch.all(c[..., cout - split:] == -5.0)
+    got = torch.cat((a[..., 8:8 + split], c[..., :cout - split]), -1).permute(0, 3, 1, 2)
+    assert torch.equal(got, want)
+    # bad split points are rejected
+    assert L.LIB.yamd_conv2d_bias_act_split(ctypes.byref(d), xin.data_ptr(), cin, wd.data_ptr(), bd.data_ptr(), y1.data_ptr(),
+                                            y1.shape[-1], y2.data_ptr(), y2.shape[-1], split + 4, Bn, H, W, L.current_stream()) != 0

@@ -136,9 +136,37 @@ extern "C" int yamd_conv_pack_weights(const yamd_conv_desc *d, const float *w, i
     return YAMD_OK;
 }
 
+namespace {
+int conv_impl(const yamd_conv_desc *d, const void *x, int x_cstride, const void *w_packed, const float *bias_packed,
+              const void *residual, int res_cstride, void *y, int y_cstride, void *y2, int y2_cstride, int split, int batch, int h,
+              int w, void *stream);
+}
+
 extern "C" int yamd_conv2d_bias_act(const yamd_conv_desc *d, const void *x, int x_cstride, const void *w_packed,
                                     const float *bias_packed, const void *residual, int res_cstride, void *y,
                                     int y_cstride, int batch, int h, int w, void *stream)
+{
+    YAMD_REQUIRE(d, "null argument");
+    return conv_impl(d, x, x_cstride, w_packed, bias_packed, residual, res_cstride, y, y_cstride, nullptr, 0, d->cout, batch, h, w,
+                     stream);
+}
+
+extern "C" int yamd_conv2d_bias_act_split(const yamd_conv_desc *d, const void *x, int x_cstride, const void *w_packed,
+                                          const float *bias_packed, void *y, int y_cstride, void *y2, int y2_cstride,
+                                          int split_cout, int batch, int h, int w, void *stream)
+{
+    YAMD_REQUIRE(d && y2, "null argument");
+    YAMD_REQUIRE(!d->out_f32, "split output is built for bf16 outputs");
+    YAMD_REQUIRE(split_cout > 0 && split_cout < d->cout && split_cout % 8 == 0, "split at cout %d of %d", split_cout, d->cout);
+    YAMD_REQUIRE(y_cstride >= split_cout && y2_cstride >= d->cout - split_cout && y2_cstride % 8 == 0 && ((uintptr_t)y2 % 16) == 0,
+                 "split outputs need 16-byte aligned pixels (cstrides %d, %d)", y_cstride, y2_cstride);
+    return conv_impl(d, x, x_cstride, w_packed, bias_packed, nullptr, 0, y, y_cstride, y2, y2_cstride, split_cout, batch, h, w, stream);
+}
+
+namespace {
+int conv_impl(const yamd_conv_desc *d, const void *x, int x_cstride, const void *w_packed, const float *bias_packed,
+              const void *residual, int res_cstride, void *y, int y_cstride, void *y2, int y2_cstride, int split, int batch, int h,
+              int w, void *stream)
 {
     YAMD_REQUIRE(d && x && w_packed && bias_packed && y, "null argument");
     YAMD_REQUIRE(batch > 0 && h > 0 && w > 0, "bad shape %dx%dx%d", batch, h, w);
@@ -147,7 +175,7 @@ extern "C" int yamd_conv2d_bias_act(const yamd_conv_desc *d, const void *x, int 
                  "input needs 16-byte aligned pixels (cstride=%d)", x_cstride);
     YAMD_REQUIRE(((uintptr_t)w_packed % 16) == 0, "packed weights must be 16-byte aligned");
     if (!d->out_f32) {
-        YAMD_REQUIRE(y_cstride >= d->cout && y_cstride % 8 == 0 && ((uintptr_t)y % 16) == 0,
+        YAMD_REQUIRE(y_cstride >= (split < d->cout ? split : d->cout) && y_cstride % 8 == 0 && ((uintptr_t)y % 16) == 0,
                      "bf16 output needs 16-byte aligned pixels (cstride=%d)", y_cstride);
         if (residual)
             YAMD_REQUIRE(res_cstride >= d->cout && res_cstride % 4 == 0 && ((uintptr_t)residual % 8) == 0,
@@ -162,6 +190,9 @@ extern "C" int yamd_conv2d_bias_act(const yamd_conv_desc *d, const void *x, int 
     p.bias = bias_packed;
     p.res = (const __bf16 *)residual;
     p.y = y;
+    p.y2 = (__bf16 *)y2;
+    p.y2_cs = y2_cstride;
+    p.split = split;
     p.x_cs = x_cstride;
     p.res_cs = res_cstride;
     p.y_cs = y_cstride;
@@ -189,3 +220,4 @@ extern "C" int yamd_conv2d_bias_act(const yamd_conv_desc *d, const void *x, int 
               d->ck, d->out_f32, d->nwaves);
     return YAMD_EINVAL;
 }
+}  // namespace

@@ -35,7 +35,8 @@ struct ConvParams {
     const float *bias;
     const __bf16 *res;
     void *y;
-    int x_cs, res_cs, y_cs;
+    __bf16 *y2;                  // bf16 output only: couts >= split go to y2 (at channel cout - split), the others to y
+    int x_cs, res_cs, y_cs, y2_cs, split;
     int H, W, Hout, Wout, Cout;
     int TH, tiles_x, tiles_y, n_tiles, nchunks;
     int act;
@@ -363,8 +364,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_kernel(Co
                 const int pq = wave * (32 * MREP) + m * 32 + r;
                 const int qr = pq / TW, qc = pq % TW;
                 const int co = nt * (NREP * 32) + piece * 8;
-                if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout && co < p.Cout)
-                    *(uint4 *)((__bf16 *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + co) = v;
+                if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout && co < p.Cout) {
+                    const size_t opix = (size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc;
+                    __bf16 *dst = co < p.split ? (__bf16 *)p.y + opix * p.y_cs + co : p.y2 + opix * p.y2_cs + (co - p.split);
+                    *(uint4 *)dst = v;
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();

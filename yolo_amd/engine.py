@@ -101,7 +101,10 @@ class Program:
         return y
 
     def conv(self, name: str, x: View, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, act: int,
-             out: Optional[View] = None, residual: Optional[View] = None, out_f32: bool = False) -> View:
+             out: Optional[View] = None, residual: Optional[View] = None, out_f32: bool = False,
+             out2: Optional[View] = None) -> View:
+        """``out2``: the last ``out2.c`` output channels go to that view instead, the first ``cout - out2.c`` to ``out``
+        (one conv computing two branches whose consumers want each branch densely packed)."""
         k = weight.shape[-1]
         cout = weight.shape[0]
         pad = k // 2
@@ -110,13 +113,17 @@ class Program:
         from . import tuning
         layer = ConvLayer(name, weight, bias, stride, act, x.c, out_f32,
                           None if out_f32 else tuning.lookup(k, stride, x.c, cout, ho, wo))
-        if out is None:
-            out = self.buffer(ho, wo, cout, torch.float32 if out_f32 else torch.bfloat16)
-        assert (out.h, out.w, out.c) == (ho, wo, cout), (name, out, ho, wo, cout)
+        if out2 is not None:
+            assert out is not None and residual is None and not out_f32
+            assert (out.h, out.w, out2.h, out2.w) == (ho, wo, ho, wo) and out.c + out2.c == cout and out.c % 8 == 0
+        else:
+            if out is None:
+                out = self.buffer(ho, wo, cout, torch.float32 if out_f32 else torch.bfloat16)
+            assert (out.h, out.w, out.c) == (ho, wo, cout), (name, out, ho, wo, cout)
         if residual is not None:
             assert (residual.h, residual.w, residual.c) == (ho, wo, cout)
         self.convs.append(layer)
-        self.ops.append(("conv", layer, x, out, residual))
+        self.ops.append(("conv", layer, x, out, residual, out2))
         return out
 
     def upsample2x(self, x: View, out: Optional[View] = None) -> View:
@@ -206,9 +213,10 @@ class Program:
         for op in self.ops:
             if op[0] != "conv" or op[1].desc.out_f32:
                 continue
-            _, layer, x, out, res = op
+            _, layer, x, out, res, out2 = op
             k, s = layer._args[0], layer._args[1]
-            key = tuning.key(k, s, x.c, out.c, out.h, out.w)
+            cout = out.c + (out2.c if out2 is not None else 0)
+            key = tuning.key(k, s, x.c, cout, out.h, out.w)
             if key in best:
                 layer.pack(best[key])
                 layer.to(device)
@@ -217,7 +225,7 @@ class Program:
             yp, ycs = self._ptr(bufs, out)
             rp, rcs = self._ptr(bufs, res) if res is not None else (None, 0)
             results = []
-            for cand in tuning.candidates(k, s, x.c, out.c):
+            for cand in tuning.candidates(k, s, x.c, cout):
                 try:
                     layer.pack(cand)
                 except _lib.YamdError:
@@ -225,8 +233,14 @@ class Program:
                 layer.to(device)
 
                 def run():
-                    _lib.check(LIB.yamd_conv2d_bias_act(ctypes.byref(layer.desc), xp, xcs, layer.w_dev.data_ptr(),
-                                                        layer.b_dev.data_ptr(), rp, rcs, yp, ycs, batch, x.h, x.w, st))
+                    if out2 is not None:
+                        y2p, y2cs = self._ptr(bufs, out2)
+                        _lib.check(LIB.yamd_conv2d_bias_act_split(ctypes.byref(layer.desc), xp, xcs, layer.w_dev.data_ptr(),
+                                                                  layer.b_dev.data_ptr(), yp, ycs, y2p, y2cs, out.c, batch,
+                                                                  x.h, x.w, st))
+                    else:
+                        _lib.check(LIB.yamd_conv2d_bias_act(ctypes.byref(layer.desc), xp, xcs, layer.w_dev.data_ptr(),
+                                                            layer.b_dev.data_ptr(), rp, rcs, yp, ycs, batch, x.h, x.w, st))
                 try:
                     run()
                 except _lib.YamdError:
@@ -264,11 +278,12 @@ class Program:
         element counted once (bf16 = 2 bytes), weights once."""
         kind = op[0]
         if kind == "conv":
-            _, layer, x, out, res = op
+            _, layer, x, out, res, out2 = op
             px = batch * out.h * out.w
             flops = 2.0 * layer.macs_per_pixel * px
             ob = 4 if layer.desc.out_f32 else 2
-            byts = batch * x.h * x.w * layer.cin_real * 2 + px * out.c * ob + layer.macs_per_pixel * 2
+            cout = out.c + (out2.c if out2 is not None else 0)
+            byts = batch * x.h * x.w * layer.cin_real * 2 + px * cout * ob + layer.macs_per_pixel * 2
             if res is not None:
                 byts += px * out.c * 2
             return flops, float(byts)
@@ -322,13 +337,19 @@ class Program:
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
             if kind == "conv":
-                _, layer, x, out, res = op
+                _, layer, x, out, res, out2 = op
                 xp, xcs = P(bufs, x)
                 yp, ycs = P(bufs, out)
-                rp, rcs = P(bufs, res) if res is not None else (None, 0)
-                _lib.check(LIB.yamd_conv2d_bias_act(ctypes.byref(layer.desc), xp, xcs, layer.w_dev.data_ptr(),
-                                                    layer.b_dev.data_ptr(), rp, rcs, yp, ycs, B, x.h, x.w, st),
-                           f"conv[{layer.name}]")
+                if out2 is not None:
+                    y2p, y2cs = P(bufs, out2)
+                    _lib.check(LIB.yamd_conv2d_bias_act_split(ctypes.byref(layer.desc), xp, xcs, layer.w_dev.data_ptr(),
+                                                              layer.b_dev.data_ptr(), yp, ycs, y2p, y2cs, out.c, B, x.h, x.w, st),
+                               f"conv[{layer.name}]")
+                else:
+                    rp, rcs = P(bufs, res) if res is not None else (None, 0)
+                    _lib.check(LIB.yamd_conv2d_bias_act(ctypes.byref(layer.desc), xp, xcs, layer.w_dev.data_ptr(),
+                                                        layer.b_dev.data_ptr(), rp, rcs, yp, ycs, B, x.h, x.w, st),
+                               f"conv[{layer.name}]")
             elif kind == "focus":
                 yp, ycs = P(bufs, op[1])
                 _lib.check(LIB.yamd_focus_pack(images.data_ptr(), yp, ycs, B, H, W, st), "focus")

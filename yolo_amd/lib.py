@@ -17,7 +17,7 @@ DECODE_V5, DECODE_V3, DECODE_POSE, DECODE_FACE = 0, 1, 2, 3
 
 # every symbol include/yolo_amd.h declares
 EXPORTS = [
-    "yamd_last_error", "yamd_version", "yamd_conv_desc_init", "yamd_conv_desc_tune", "yamd_conv_pack_weights", "yamd_conv2d_bias_act",
+    "yamd_last_error", "yamd_version", "yamd_conv_desc_init", "yamd_conv_desc_tune", "yamd_conv_pack_weights", "yamd_conv2d_bias_act", "yamd_conv2d_bias_act_split",
     "yamd_focus_pack", "yamd_nchw_to_nhwc16", "yamd_upsample2x", "yamd_maxpool2", "yamd_maxpool5_cascade", "yamd_maxpool3_cascade",
     "yamd_copy_channels", "yamd_depth_to_space2", "yamd_decode_ltrb_points",
     "yamd_decode_anchor", "yamd_decode_dfl", "yamd_nms_workspace_bytes", "yamd_nms_batched", "yamd_compact_rows", "yamd_letterbox_workspace_bytes", "yamd_letterbox_u8", "yamd_detect_match",
@@ -53,6 +53,8 @@ def _load() -> ctypes.CDLL:
     lib.yamd_conv_pack_weights.argtypes = [P(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p]
     lib.yamd_conv2d_bias_act.argtypes = [P(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                          c_int, c_int, c_int, c_int, c_void_p]
+    lib.yamd_conv2d_bias_act_split.argtypes = [P(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                               c_int, c_int, c_int, c_int, c_void_p]
     lib.yamd_focus_pack.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.yamd_nchw_to_nhwc16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.yamd_upsample2x.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]

@@ -93,12 +93,20 @@ class _Builder:
         h = m.cv1.conv.out_channels
         n = len(m.m)
         assert n >= 1
-        buf = self.p.buffer(x.h, x.w, 3 * h)
         w1, b1 = self._folded(m.cv1)
         w2, b2 = self._folded(m.cv2)
-        self.p.conv(f"{name}.cv2+cv1", x, torch.cat((w2, w1), 0), torch.cat((b2, b1), 0), 1, _lib.ACT_SILU,
-                    out=buf.slice(h, 2 * h))
-        a = buf.slice(2 * h, h)
+        if h * 2 < 128:
+            # a 64-byte channel slice of a 192-byte pixel costs a whole 128-byte memory line per read: the cv1 branch
+            # (read twice: bottleneck input and residual) gets a buffer of its own, [m out | cv2] stays line aligned
+            buf = self.p.buffer(x.h, x.w, 2 * h)
+            a = self.p.buffer(x.h, x.w, h)
+            self.p.conv(f"{name}.cv2+cv1", x, torch.cat((w2, w1), 0), torch.cat((b2, b1), 0), 1, _lib.ACT_SILU,
+                        out=buf.slice(h, h), out2=a)
+        else:
+            buf = self.p.buffer(x.h, x.w, 3 * h)
+            self.p.conv(f"{name}.cv2+cv1", x, torch.cat((w2, w1), 0), torch.cat((b2, b1), 0), 1, _lib.ACT_SILU,
+                        out=buf.slice(h, 2 * h))
+            a = buf.slice(2 * h, h)
         for i, bot in enumerate(m.m):
             t = self.cbs(f"{name}.m.{i}.cv1", bot.cv1, a)
             a = self.cbs(f"{name}.m.{i}.cv2", bot.cv2, t, out=buf.slice(0, h) if i == n - 1 else None,
