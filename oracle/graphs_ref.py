@@ -335,8 +335,11 @@ def v6face_body(sd: SD, images: torch.Tensor) -> List[torch.Tensor]:
         def pred(conv_list, pred_list):
             f = _v6_w(sd, f"{h}{conv_list}.{i}", s_, 1, silu)
             return F.conv2d(f, sd[f"{h}{pred_list}.{i}.weight"], sd[f"{h}{pred_list}.{i}.bias"])
-        outs.append(torch.cat((pred("reg_conv_list", "reg_predict_list"), pred("reg_point_conv_list", "reg_point_predict_list"),
-                               pred("cls_conv_list", "cls_predict_list")), 1))
+        parts = [pred("reg_conv_list", "reg_predict_list")]
+        if f"{h}reg_point_predict_list.{i}.weight" in sd:          # the detect head (yolov6/YoloV6Body.py) has no landmarks
+            parts.append(pred("reg_point_conv_list", "reg_point_predict_list"))
+        parts.append(pred("cls_conv_list", "cls_predict_list"))
+        outs.append(torch.cat(parts, 1))
     return outs
 
 
@@ -384,6 +387,11 @@ def model_ref(name: str):
                     decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "pose",
                                                                              point_num=p.point_num, clamp_points=predict),
                     nms=dict(in_fmt="cxcywh", point_num=17, point_conf=True))
+    if name == "v6":
+        return dict(body=v6face_body,
+                    decode=lambda raws, p, predict: decode_ref.decode_ltrb_points(raws, p.strides, 0, p.class_num,
+                                                                                  "xyxy" if predict else "cxcywh"),
+                    nms=dict(in_fmt="xyxy"))
     if name == "v6face":
         return dict(body=v6face_body,
                     decode=lambda raws, p, predict: decode_ref.decode_ltrb_points(raws, p.strides, p.point_num, p.class_num,

@@ -17,7 +17,7 @@ extern "C" int conv_trace_run(const void *x, int x_cs, const void *w, const floa
 {
     constexpr int KS = TR_KS, S = TR_S, TW = TR_TW, MREP = TR_MREP, NREP = TR_NREP, CK = TR_CK;
     ConvParams p;
-    p.x = (const __bf16 *)x; p.w = (const char *)w; p.bias = bias; p.res = nullptr; p.y = y;
+    p.x = (const __bf16 *)x; p.w = (const char *)w; p.bias = bias; p.res = nullptr; p.y = y; p.y2 = nullptr; p.y2_cs = 0; p.split = cout;
     p.x_cs = x_cs; p.res_cs = 0; p.y_cs = y_cs; p.H = h; p.W = wd;
     const int pad = KS / 2;
     p.Hout = (h + 2 * pad - KS) / S + 1; p.Wout = (wd + 2 * pad - KS) / S + 1; p.Cout = cout; p.act = YAMD_ACT_SILU;

@@ -9,7 +9,8 @@ so = os.path.join(ROOT, "scratch", f"libconv_trace_{k}{s}_{tw}_{mrep}{nrep}_{ck}
 lib = ctypes.CDLL(so)
 d = L.ConvDesc()
 L.check(L.LIB.yamd_conv_desc_init(ctypes.byref(d), k, s, cin, cout, 1, 0))
-assert (d.mrep, d.nrep, d.ck) == (mrep, nrep, ck), (d.mrep, d.nrep, d.ck)
+if (d.mrep, d.nrep, d.ck) != (mrep, nrep, ck):
+    L.check(L.LIB.yamd_conv_desc_tune(ctypes.byref(d), mrep, nrep, ck, 4))
 w = torch.randn(cout, cin, k, k) * 0.05
 wp = torch.empty(d.packed_w_elems, dtype=torch.int16); bp = torch.empty(d.cout_pad)
 L.check(L.LIB.yamd_conv_pack_weights(ctypes.byref(d), w.data_ptr(), cin, torch.zeros(cout).data_ptr(), wp.data_ptr(), bp.data_ptr()))

@@ -98,7 +98,7 @@ def _bifusion(cins, cout) -> nn.Module:
     return m
 
 
-def _tree(param: Yolo6FaceParam) -> nn.Module:
+def _tree(param) -> nn.Module:
     if param.m_type not in _CFG:
         raise NotImplementedError(f"YoloV6Face m_type={param.m_type!r}: only the n/s variants are built on the HIP path")
     dm, wm = _CFG[param.m_type]
@@ -132,14 +132,16 @@ def _tree(param: Yolo6FaceParam) -> nn.Module:
     body.neck_network = nk
     hd = nn.Module()
     hc = [ch[8], ch[9], ch[10], ch[11]][:param.num_layers] if param.num_layers == 4 else [ch[6], ch[8], ch[10]]
-    nc, P = param.class_num, param.point_num
+    nc, P = param.class_num, getattr(param, "point_num", 0)
     hd.stems = nn.ModuleList(_wrapped(c, c, 1) for c in hc)
     hd.cls_conv_list = nn.ModuleList(_wrapped(c, c, 3) for c in hc)
     hd.reg_conv_list = nn.ModuleList(_wrapped(c, c, 3) for c in hc)
-    hd.reg_point_conv_list = nn.ModuleList(_wrapped(c, c, 3) for c in hc)
+    if P:
+        hd.reg_point_conv_list = nn.ModuleList(_wrapped(c, c, 3) for c in hc)
     hd.cls_predict_list = nn.ModuleList(nn.Conv2d(c, nc, 1) for c in hc)
     hd.reg_predict_list = nn.ModuleList(nn.Conv2d(c, 4, 1) for c in hc)
-    hd.reg_point_predict_list = nn.ModuleList(nn.Conv2d(c, 2 * P, 1) for c in hc)
+    if P:
+        hd.reg_point_predict_list = nn.ModuleList(nn.Conv2d(c, 2 * P, 1) for c in hc)
     hd.proj = nn.Parameter(torch.linspace(0, 16, 17), requires_grad=False)
     for conv in hd.cls_predict_list:                 # YoloV6FaceHead.initialize_biases (:1289-1314)
         conv.bias.data.fill_(-math.log((1 - 1e-2) / 1e-2))
@@ -158,6 +160,7 @@ class YoloV6Face(TaskModel):
     def __init__(self, param: Yolo6FaceParam):
         super().__init__()
         self.param = param
+        self.point_num = getattr(param, "point_num", 0)
         self.yolo_body = _tree(param)
         self.eval()
 
@@ -219,14 +222,15 @@ class YoloV6Face(TaskModel):
         pan1 = self._rb(R, "Rep_n5", nk.Rep_n5, P.cat([self._w(R, "down_sample_1", nk.down_sample_1, pan2, relu), fpn1]))
         pan0 = self._rb(R, "Rep_n6", nk.Rep_n6, P.cat([self._w(R, "down_sample_0", nk.down_sample_0, pan1, relu), fpn0]))
 
-        nc, K = self.param.class_num, 2 * self.param.point_num
+        nc, K = self.param.class_num, 2 * self.point_num
         for i, t in enumerate((pan3, pan2, pan1, pan0)[:self.param.num_layers]):
             raw = P.buffer(t.h, t.w, 4 + K + nc, torch.float32, name=f"raw{i}")       # [ltrb | landmarks | cls]
             s = self._w(R, f"head.stems.{i}", hd.stems[i], t, silu)
             R.head(f"head.reg_pred.{i}", hd.reg_predict_list[i],
                    self._w(R, f"head.reg_conv.{i}", hd.reg_conv_list[i], s, silu), out=raw.slice(0, 4))
-            R.head(f"head.point_pred.{i}", hd.reg_point_predict_list[i],
-                   self._w(R, f"head.point_conv.{i}", hd.reg_point_conv_list[i], s, silu), out=raw.slice(4, K))
+            if K:
+                R.head(f"head.point_pred.{i}", hd.reg_point_predict_list[i],
+                       self._w(R, f"head.point_conv.{i}", hd.reg_point_conv_list[i], s, silu), out=raw.slice(4, K))
             R.head(f"head.cls_pred.{i}", hd.cls_predict_list[i],
                    self._w(R, f"head.cls_conv.{i}", hd.cls_conv_list[i], s, silu), out=raw.slice(4 + K, nc))
             P.outputs[f"L{i}"] = raw
@@ -239,7 +243,7 @@ class YoloV6Face(TaskModel):
         return [out[f"L{i}"] for i in range(self.param.num_layers)]
 
     def _decode(self, raws, fmt: str) -> torch.Tensor:
-        return torch_utils.decode_ltrb_points(raws, self.param.strides, self.param.point_num, self.param.class_num, fmt)
+        return torch_utils.decode_ltrb_points(raws, self.param.strides, self.point_num, self.param.class_num, fmt)
 
     def _forward(self, images: torch.Tensor) -> List[torch.Tensor]:
         """[(B, A, 5+2P+nc)]: cxcywh, 1.0, landmarks, class scores (YoloV6Face.py:42-58)."""
@@ -249,11 +253,12 @@ class YoloV6Face(TaskModel):
         """Inference entries of YoloV6Face.py:23-40 (the anchor boxes used only by the loss are left out)."""
         raws = self.raw_heads(tensor_dict["batch_images"])
         pred = self._decode(raws, "xyxy")
-        K = 2 * self.param.point_num
+        K = 2 * self.point_num
         B = pred.shape[0]
         tensor_dict["cls_score_tensor"] = pred[..., 5 + K:]
         tensor_dict["predict_xy_xy"] = pred[..., :4]
-        tensor_dict["point_predict_xy"] = pred[..., 5:5 + K]
+        if K:
+            tensor_dict["point_predict_xy"] = pred[..., 5:5 + K]
         tensor_dict["reg_distribute_tensor"] = torch.cat([r[..., :4].reshape(B, -1, 4) for r in raws], 1)
         tensor_dict["num_anchors_list"] = [r.shape[1] * r.shape[2] for r in raws]
         tensor_dict["stride_tensor"] = torch.cat([torch.full((r.shape[1] * r.shape[2], 1), float(s), device=pred.device)
@@ -266,7 +271,7 @@ class YoloV6Face(TaskModel):
 
     def nms_predict(self, pred: torch.Tensor):
         rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "xyxy", self.param.conf_threshold,
-                                                  self.param.nms_threshold, 2 * self.param.point_num)
+                                                  self.param.nms_threshold, 2 * self.point_num)
         return rows, counts
 
     def predict(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:
@@ -291,3 +296,14 @@ class YoloV6Face(TaskModel):
                     del m.rbr_identity
                 m.rbr_identity = None
         self.invalidate()
+
+
+class YoloV6(YoloV6Face):
+    """``YoloV6(param)`` (detect, n/s): the graph of luoyang/yolov6/YoloV6Body.py is the face graph without the landmark
+    branch of the head (five modules per level instead of seven, :1071-1165, :1245-1252); ``_forward`` /
+    ``predict`` as luoyang/yolov6/YoloV6.py:41-83.  ``predicts`` rows: [x1,y1,x2,y2, 1.0, cls_conf, cls_id]."""
+
+    def __init__(self, param):
+        if getattr(param, "point_num", 0):
+            raise ValueError("YoloV6 (detect) takes a Yolo6Param; use YoloV6Face for landmark heads")
+        super().__init__(param)
