@@ -275,6 +275,8 @@ def _ref_models():
         "v7pose": (YoloV7Pose, lambda: Yolo7PoseParam(m_type="l"), "desc", 6 + 3 * 17 + 1, 64),
         "v6face": (YoloV6Face, lambda: Yolo6FaceParam(m_type="s"), "v6", 6 + 2 * 5 + 1, 128),
         "v6": (_lazy("luoyang.yolov6.YoloV6", "YoloV6"), lambda: _lazy("luoyang.param.Param", "Yolo6Param")(m_type="s"), "v6", 7, 128),
+        "v6pose": (_lazy("luoyang.yolov6_pose.YoloV6Pose", "YoloV6Pose"), lambda: _lazy("luoyang.param.Param", "Yolo6PoseParam")(m_type="s"),
+                   "v6", 6 + 3 * 17 + 1, 128),
         "v7": (_lazy("luoyang.yolov7.YoloV7", "YoloV7"), lambda: _lazy("luoyang.param.Param", "Yolo7Param")(m_type="l"), "desc", 7, 64),
         "v7face": (_lazy("luoyang.yolov7_face.YoloV7Face", "YoloV7Face"), lambda: _lazy("luoyang.param.Param", "Yolo7FaceParam")(m_type="l"),
                    "desc", 6 + 2 * 5 + 1, 64),
@@ -301,6 +303,9 @@ def _v6_raw_heads(model, imgs):
         cls = hd.cls_predict_list[i](hd.cls_conv_list[i](s))
         if hasattr(hd, "reg_point_predict_list"):
             pts = hd.reg_point_predict_list[i](hd.reg_point_conv_list[i](s))
+            nc = hd.num_classes
+            if cls.shape[1] > nc:          # pose: the class conv also emits the keypoint confidences, stored first here
+                cls = torch.cat((cls[:, nc:], cls[:, :nc]), 1)
             outs.append(torch.cat((reg, pts, cls), 1))
         else:
             outs.append(torch.cat((reg, cls), 1))

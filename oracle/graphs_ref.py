@@ -346,6 +346,19 @@ def v6face_body(sd: SD, images: torch.Tensor) -> List[torch.Tensor]:
 # ------------------------------------------------------------------------------------------------
 # per-model glue: body graph, decode of its raw heads, NMS flavour of its predict()
 # ------------------------------------------------------------------------------------------------
+def v6pose_body(sd: SD, images: torch.Tensor) -> List[torch.Tensor]:
+    """The v6 pose graph = the face graph; its class conv emits [classes | keypoint confidences]
+    (luoyang/yolov6_pose/YoloV6PoseBody.py:1412-1430).  Returned per level as [ltrb | keypoints | confidences | classes],
+    the column order of YoloV6Pose._forward (luoyang/yolov6_pose/YoloV6Pose.py:43-63)."""
+    outs = []
+    for i, r in enumerate(v6face_body(sd, images)):
+        P = sd[f"yolo_body.head.reg_point_predict_list.{i}.weight"].shape[0] // 2
+        k = 4 + 2 * P
+        nc = r.shape[1] - k - P
+        outs.append(torch.cat((r[:, :k], r[:, k + nc:], r[:, k:k + nc]), 1))
+    return outs
+
+
 def model_ref(name: str):
     """dict(body=fn(sd, images)->raws NCHW ascending stride, decode=fn(raws_np, param, predict)->(B,A,C),
     nms=kwargs of oracle.postprocess.non_max_suppression used by the reference's predict())."""
@@ -392,6 +405,12 @@ def model_ref(name: str):
                     decode=lambda raws, p, predict: decode_ref.decode_ltrb_points(raws, p.strides, 0, p.class_num,
                                                                                   "xyxy" if predict else "cxcywh"),
                     nms=dict(in_fmt="xyxy"))
+    if name == "v6pose":
+        return dict(body=v6pose_body,
+                    decode=lambda raws, p, predict: decode_ref.decode_ltrb_points(raws, p.strides, p.point_num,
+                                                                                  p.class_num + p.point_num,
+                                                                                  "xyxy" if predict else "cxcywh"),
+                    nms=dict(in_fmt="xyxy", point_num=17, point_conf=True))
     if name == "v6face":
         return dict(body=v6face_body,
                     decode=lambda raws, p, predict: decode_ref.decode_ltrb_points(raws, p.strides, p.point_num, p.class_num,

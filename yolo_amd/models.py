@@ -10,7 +10,7 @@ def registry() -> Dict[str, Dict[str, Any]]:
     from .yolov4 import YoloV4
     from .yolov5 import YoloV5
     from .yolov5_face import YoloV5Face, YoloV5Pose
-    from .yolov6_face import YoloV6, YoloV6Face
+    from .yolov6_face import YoloV6, YoloV6Face, YoloV6Pose
     from .yolov7 import YoloV7, YoloV7Face
     from .yolov7_pose import YoloV7Pose
     from .yolov8 import YoloV8
@@ -36,6 +36,10 @@ def registry() -> Dict[str, Dict[str, Any]]:
         "v6": dict(cls=YoloV6, param=lambda: _param.Yolo6Param(m_type="s"),
                    init=dict(scale={".rbr_dense.bn.weight": 0.55, ".rbr_1x1.bn.weight": 0.55,
                                     ".rbr_identity.weight": 0.55, "reg_predict_list": 0.3})),
+        "v6pose": dict(cls=YoloV6Pose, param=lambda: _param.Yolo6PoseParam(m_type="s"),
+                       init=dict(scale={".rbr_dense.bn.weight": 0.55, ".rbr_1x1.bn.weight": 0.55,
+                                        ".rbr_identity.weight": 0.55, "reg_predict_list": 0.3,
+                                        "reg_point_predict_list": 0.3})),
         "v6face": dict(cls=YoloV6Face, param=lambda: _param.Yolo6FaceParam(m_type="s"),
                        init=dict(scale={".rbr_dense.bn.weight": 0.55, ".rbr_1x1.bn.weight": 0.55,
                                         ".rbr_identity.weight": 0.55, "reg_predict_list": 0.3,
@@ -132,14 +136,20 @@ def from_state_dict(sd, img_size: int, output_size: int = 0, point_num: int = 0)
         t = width_type(sd[k].shape[0], {"n": 32, "s": 64})
         from .yolov6_face import YoloV6
         pk = "yolo_body.head.reg_point_predict_list.0.weight"
-        if pk in keys:                                        # landmark branch present: the face model
+        from .yolov6_face import YoloV6Pose
+        if pk in keys and (point_num >= 10 or (point_num == 0 and sd[pk].shape[0] // 2 >= 10)):
+            # many keypoints: the pose model, whose class conv also carries one confidence per keypoint
+            p, cls = _param.Yolo6PoseParam(m_type=t), YoloV6Pose
+            p.point_num = sd[pk].shape[0] // 2
+        elif pk in keys:                                      # landmark branch present: the face model
             p, cls = _param.Yolo6FaceParam(m_type=t), YoloV6Face
             p.point_num = sd[pk].shape[0] // 2
         else:
             p, cls = _param.Yolo6Param(m_type=t), YoloV6
         p.num_layers = sum(1 for q in keys if q.startswith("yolo_body.head.stems.") and q.endswith("conv.weight"))
         p.strides = [8, 16, 32, 64][:p.num_layers]
-        p = with_classes(p, sd["yolo_body.head.cls_predict_list.0.weight"].shape[0])
+        p = with_classes(p, sd["yolo_body.head.cls_predict_list.0.weight"].shape[0]
+                         - (p.point_num if getattr(p, "point_conf", False) else 0))
     else:
         raise ValueError("checkpoint does not belong to a model family built on the HIP path")
     p.set_img_size(img_size)

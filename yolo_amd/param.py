@@ -139,6 +139,21 @@ class Yolo6Param(Param):
         self.set_img_size(640)
 
 
+class Yolo6PoseParam(Param):
+    def __init__(self, batch_size: int = 6, m_type: str = "s"):
+        super().__init__(batch_size)
+        assert m_type in ("n", "s", "m", "l")
+        self.m_type = m_type
+        self.use_dfl = m_type in ("m", "l")
+        self.pretrain_path = None
+        self._names(["person"])
+        self.num_layers = 4
+        self.strides = [8, 16, 32, 64]
+        self.point_num = 17
+        self.point_conf = True          # the head carries one confidence per keypoint
+        self.set_img_size(640)
+
+
 class Yolo6FaceParam(Param):
     def __init__(self, batch_size: int = 6, m_type: str = "s"):
         super().__init__(batch_size)

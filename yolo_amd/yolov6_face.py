@@ -138,7 +138,8 @@ def _tree(param) -> nn.Module:
     hd.reg_conv_list = nn.ModuleList(_wrapped(c, c, 3) for c in hc)
     if P:
         hd.reg_point_conv_list = nn.ModuleList(_wrapped(c, c, 3) for c in hc)
-    hd.cls_predict_list = nn.ModuleList(nn.Conv2d(c, nc, 1) for c in hc)
+    ncp = nc + (P if getattr(param, "point_conf", False) else 0)     # pose: one confidence logit per keypoint after the classes
+    hd.cls_predict_list = nn.ModuleList(nn.Conv2d(c, ncp, 1) for c in hc)
     hd.reg_predict_list = nn.ModuleList(nn.Conv2d(c, 4, 1) for c in hc)
     if P:
         hd.reg_point_predict_list = nn.ModuleList(nn.Conv2d(c, 2 * P, 1) for c in hc)
@@ -161,6 +162,7 @@ class YoloV6Face(TaskModel):
         super().__init__()
         self.param = param
         self.point_num = getattr(param, "point_num", 0)
+        self.point_conf = bool(getattr(param, "point_conf", False)) and self.point_num > 0
         self.yolo_body = _tree(param)
         self.eval()
 
@@ -223,27 +225,36 @@ class YoloV6Face(TaskModel):
         pan0 = self._rb(R, "Rep_n6", nk.Rep_n6, P.cat([self._w(R, "down_sample_0", nk.down_sample_0, pan1, relu), fpn0]))
 
         nc, K = self.param.class_num, 2 * self.point_num
+        ncp = nc + (self.point_num if self.point_conf else 0)
         for i, t in enumerate((pan3, pan2, pan1, pan0)[:self.param.num_layers]):
-            raw = P.buffer(t.h, t.w, 4 + K + nc, torch.float32, name=f"raw{i}")       # [ltrb | landmarks | cls]
+            raw = P.buffer(t.h, t.w, 4 + K + ncp, torch.float32, name=f"raw{i}")      # [ltrb | landmarks | (kpt conf) | cls]
             s = self._w(R, f"head.stems.{i}", hd.stems[i], t, silu)
             R.head(f"head.reg_pred.{i}", hd.reg_predict_list[i],
                    self._w(R, f"head.reg_conv.{i}", hd.reg_conv_list[i], s, silu), out=raw.slice(0, 4))
             if K:
                 R.head(f"head.point_pred.{i}", hd.reg_point_predict_list[i],
                        self._w(R, f"head.point_conv.{i}", hd.reg_point_conv_list[i], s, silu), out=raw.slice(4, K))
-            R.head(f"head.cls_pred.{i}", hd.cls_predict_list[i],
-                   self._w(R, f"head.cls_conv.{i}", hd.cls_conv_list[i], s, silu), out=raw.slice(4 + K, nc))
+            cp = hd.cls_predict_list[i]
+            cw, cb = cp.weight.detach(), cp.bias.detach()
+            if self.point_conf:
+                # the reference's conv emits [classes | keypoint confidences] (YoloV6PoseBody.py:1412-1430); rows follow
+                # the order of its output columns, confidences first, so the kernel can treat both as "scores"
+                cw, cb = torch.cat((cw[nc:], cw[:nc]), 0), torch.cat((cb[nc:], cb[:nc]), 0)
+            P.conv(f"head.cls_pred.{i}", self._w(R, f"head.cls_conv.{i}", hd.cls_conv_list[i], s, silu), cw, cb, 1,
+                   _lib.ACT_NONE, out=raw.slice(4 + K, ncp), out_f32=True)
             P.outputs[f"L{i}"] = raw
         return P
 
     # ---- reference interface -------------------------------------------------------------------
     def raw_heads(self, images: torch.Tensor) -> List[torch.Tensor]:
-        """Raw head tensors per level, float32 NHWC (B,h,w,4+2P+nc), channel order [ltrb | landmarks | cls]."""
+        """Raw head tensors per level, float32 NHWC (B,h,w,4+2P+nc), channel order [ltrb | landmarks | cls]
+        (pose: [ltrb | keypoints | keypoint confidences | cls])."""
         out = self.program().run(images)
         return [out[f"L{i}"] for i in range(self.param.num_layers)]
 
     def _decode(self, raws, fmt: str) -> torch.Tensor:
-        return torch_utils.decode_ltrb_points(raws, self.param.strides, self.point_num, self.param.class_num, fmt)
+        ncp = self.param.class_num + (self.point_num if self.point_conf else 0)
+        return torch_utils.decode_ltrb_points(raws, self.param.strides, self.point_num, ncp, fmt)
 
     def _forward(self, images: torch.Tensor) -> List[torch.Tensor]:
         """[(B, A, 5+2P+nc)]: cxcywh, 1.0, landmarks, class scores (YoloV6Face.py:42-58)."""
@@ -255,7 +266,12 @@ class YoloV6Face(TaskModel):
         pred = self._decode(raws, "xyxy")
         K = 2 * self.point_num
         B = pred.shape[0]
-        tensor_dict["cls_score_tensor"] = pred[..., 5 + K:]
+        if self.point_conf:
+            tensor_dict["point_conf_tensor"] = pred[..., 5 + K:5 + K + self.point_num]
+            K_all = K + self.point_num
+        else:
+            K_all = K
+        tensor_dict["cls_score_tensor"] = pred[..., 5 + K_all:]
         tensor_dict["predict_xy_xy"] = pred[..., :4]
         if K:
             tensor_dict["point_predict_xy"] = pred[..., 5:5 + K]
@@ -271,7 +287,7 @@ class YoloV6Face(TaskModel):
 
     def nms_predict(self, pred: torch.Tensor):
         rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "xyxy", self.param.conf_threshold,
-                                                  self.param.nms_threshold, 2 * self.point_num)
+                                                  self.param.nms_threshold, (3 if self.point_conf else 2) * self.point_num)
         return rows, counts
 
     def predict(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:
@@ -306,4 +322,16 @@ class YoloV6(YoloV6Face):
     def __init__(self, param):
         if getattr(param, "point_num", 0):
             raise ValueError("YoloV6 (detect) takes a Yolo6Param; use YoloV6Face for landmark heads")
+        super().__init__(param)
+
+
+class YoloV6Pose(YoloV6Face):
+    """``YoloV6Pose(param)`` (n/s): the face graph with one confidence per keypoint, which the reference takes from the
+    class-prediction conv (``class_num + point_num`` outputs, luoyang/yolov6_pose/YoloV6PoseBody.py:1412-1430);
+    ``_forward`` / ``predict`` as luoyang/yolov6_pose/YoloV6Pose.py:43-89.
+    ``predicts`` rows: [x1,y1,x2,y2, 1.0, cls_conf, 17 x (x,y), 17 confidences, cls_id]."""
+
+    def __init__(self, param):
+        if not getattr(param, "point_conf", False):
+            raise ValueError("YoloV6Pose takes a Yolo6PoseParam")
         super().__init__(param)
