@@ -76,6 +76,9 @@ def rep_conv_equivalent(m: nn.Module):
 
 def _tree(param, anchor_num: int, cols: int) -> nn.Module:
     phi = param.m_type
+    if phi != "l":
+        raise NotImplementedError(f"YOLOv7 m_type={phi!r}: only the l width is built on the HIP path (the x width has "
+                                  "40-channel layers, for which no conv tiling exists)")
     tc = {"l": 32, "x": 40}[phi]
     bc = 32
     pc = {"l": 32, "x": 64}[phi]
