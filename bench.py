@@ -35,8 +35,8 @@ PEAK_HBM_GBS = 8000.0         # HBM3E peak of one MI355X
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="v5s", help="model family (yolo_amd.models.registry); v5s is the headline config")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the BASELINE config of the model)")
     ap.add_argument("--weights", default="torch_default", choices=["torch_default", "spread"],
@@ -83,9 +83,14 @@ def max_over_ranks(value: float, world: int, dry: bool) -> float:
 
 
 # per-GPU batch of the BASELINE configurations (v8s: 1024 images over 8 GPUs)
-DEFAULT_BATCH = {"v5s": 256, "v8s": 128, "v7pose": 512, "v6face": 512, "v3": 256, "v4": 256}
+DEFAULT_BATCH = {"v5s": 256, "v8s": 128, "v7pose": 512, "v6face": 512, "v3": 256, "v4": 256,
+                 # variants outside the BASELINE configurations: the batch of the nearest configuration
+                 "v5face": 256, "v5pose": 256, "v7": 256, "v7face": 256, "v6": 256, "v6pose": 256}
 LABEL = {"v5s": "YOLOv5s VOC-20 detect", "v8s": "YOLOv8s VOC-20 detect", "v7pose": "YOLOv7-l pose (17 keypoints)",
-         "v6face": "YOLOv6-s face (5 landmarks, 4 levels)", "v3": "YOLOv3 VOC-20 detect", "v4": "YOLOv4 VOC-20 detect"}
+         "v6face": "YOLOv6-s face (5 landmarks, 4 levels)", "v3": "YOLOv3 VOC-20 detect", "v4": "YOLOv4 VOC-20 detect",
+         "v5face": "YOLOv5s face (5 landmarks)", "v5pose": "YOLOv5s pose (17 keypoints)", "v7": "YOLOv7-l VOC-20 detect",
+         "v7face": "YOLOv7-l face (5 landmarks)", "v6": "YOLOv6-s VOC-20 detect (4 levels)",
+         "v6pose": "YOLOv6-s pose (17 keypoints, 4 levels)"}
 
 
 def build_model(name: str, weights: str):
@@ -345,7 +350,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(conv_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-                         "kernel": "conv_igemm_kernel (all %d fused conv launches of one step)" % prof["n_conv"],
+                         "kernel": "conv_igemm_kernel + stem_conv_kernel (all %d fused conv launches of one step)" % prof["n_conv"],
                          "flops_per_launch": prof["conv_flops"] / prof["n_conv"],
                          "avg_launch_ms": round(prof["conv_ms"] / prof["n_conv"], 4)},
             "stages_ms": {"conv": round(prof["conv_ms"], 3), "layout_pool_upsample": round(prof["other_ms"], 3),

@@ -217,6 +217,24 @@ int yamd_detect_match(const float *rows, const int *counts, int batch, int max_o
                       const int *target_counts, int max_targets, float img_w, float img_h, float iou_thr,
                       uint8_t *true_positive, void *stream);
 
+/* ----------------------------------------------------------------------------------------
+ * First conv of a network, straight from the fp32 NCHW images (batch,3,h,w) to NHWC bf16:
+ *   YAMD_STEM_K3S1 / YAMD_STEM_K3S2  Conv2d(3, cout, 3, stride 1 / 2, pad 1) + bias + act
+ *       (yolov8/YoloV8Body.py stem, yolov5_face/Yolov5FaceBody.py:56, yolov7_pose/YoloV7PoseBody.py stem,
+ *        yolov6_face RepVGG stem after re-parameterisation, yolov3/DarkNet53.py conv1, yolov4 first conv)
+ *   YAMD_STEM_FOCUS                  Focus (yolov5/YoloV5Body.py:54-77): space-to-depth to 12 channels, then
+ *       Conv2d(12, cout, 3, 1, 1) + bias + act, computed as one 6x6 stride-2 conv on the image
+ * Replaces yamd_focus_pack / yamd_nchw_to_nhwc16 followed by yamd_conv2d_bias_act for those layers (no padded
+ * 16-channel copy of the image is written).  Weights: (cout, 3 or 12, 3, 3) fp32 with BN folded, packed on the host.
+ * cout <= 64 and a multiple of 8; images are rounded to bf16 as in the unfused path.
+ * ---------------------------------------------------------------------------------------- */
+enum { YAMD_STEM_K3S1 = 0, YAMD_STEM_K3S2 = 1, YAMD_STEM_FOCUS = 2 };
+int64_t yamd_stem_packed_elems(int mode, int cout);   /* bf16 elements of the packed weights (bias: 64 floats) */
+int yamd_stem_pack_weights(int mode, const float *w_host, const float *bias_host, int cout, void *w_packed_host,
+                           float *bias_packed_host);
+int yamd_stem_conv(int mode, const float *images, int batch, int h, int w, const void *w_packed,
+                   const float *bias_packed, int cout, int act, void *y, int y_cstride, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

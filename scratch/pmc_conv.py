@@ -8,7 +8,7 @@ def load(d, counter):
     rows = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and "conv_igemm" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and ("conv_igemm" in r["Kernel_Name"] or "stem_conv" in r["Kernel_Name"]):
                 rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), r["Kernel_Name"]))
     rows.sort()
     return rows

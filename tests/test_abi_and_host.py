@@ -90,7 +90,9 @@ def test_v5s_state_dict_and_plan():
     assert sum(v.numel() for k, v in sd.items() if "num_batches" not in k and "running" not in k) == 7114785 - 0 \
         or True   # parameter count incl. buffers is checked through the golden load below
     prog = m.program()
-    assert len(prog.convs) == 54      # 62 convs in the reference graph; cv1+cv2 of the 8 C3 blocks run as one conv each
+    # 62 convs in the reference graph; cv1+cv2 of the 8 C3 blocks run as one conv each; the first conv runs as the
+    # from-the-image stem kernel
+    assert len(prog.convs) + len(prog.stems) == 54 and len(prog.stems) == 1
     assert abs(prog.conv_macs_per_image() * 2 / 1e9 - 16.44) < 0.01
     assert set(prog.outputs) == {"P3", "P4", "P5"}
     assert isinstance(prog, Program)

@@ -301,3 +301,40 @@ def test_conv_split_output(gpu_device, k, s, cin, cout, split, H, W):
     # bad split points are rejected
     assert L.LIB.yamd_conv2d_bias_act_split(ctypes.byref(d), xin.data_ptr(), cin, wd.data_ptr(), bd.data_ptr(), y1.data_ptr(),
                                             y1.shape[-1], y2.data_ptr(), y2.shape[-1], split + 4, Bn, H, W, L.current_stream()) != 0
+
+
+@pytest.mark.parametrize("mode,cout,H,W,act", [("k3s1", 32, 40, 72, 1), ("k3s1", 64, 33, 35, 2), ("k3s2", 32, 64, 96, 1),
+                                               ("k3s2", 48, 30, 70, 4), ("k3s2", 16, 18, 34, 3), ("focus", 32, 64, 128, 1),
+                                               ("focus", 64, 36, 44, 1)])
+def test_stem_conv_from_image(gpu_device, mode, cout, H, W, act):
+    """yamd_stem_conv against torch: 3x3 (stride 1 / 2) on the 3-channel image and the Focus variant, bf16-rounded
+    image and weights, fp32 accumulation; output written into a channel slice of a wider buffer"""
+    from yolo_amd import lib as L
+    from yolo_amd.engine import StemLayer
+    g = torch.Generator().manual_seed(H * 7 + cout)
+    Bn = 3
+    cin = 12 if mode == "focus" else 3
+    x = torch.rand((Bn, 3, H, W), generator=g)
+    w = _bf16_round(torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5)
+    b = torch.randn((cout,), generator=g) * 0.5
+    xb = _bf16_round(x)
+    if mode == "focus":
+        xf = torch.cat((xb[..., ::2, ::2], xb[..., 1::2, ::2], xb[..., ::2, 1::2], xb[..., 1::2, 1::2]), 1)
+        want = F.conv2d(xf, w, b, stride=1, padding=1)
+    else:
+        want = F.conv2d(xb, w, b, stride=1 if mode == "k3s1" else 2, padding=1)
+    want = _act(want, act)
+    layer = StemLayer("t", mode, w, b, act)
+    layer.to(gpu_device)
+    Ho, Wo = want.shape[2], want.shape[3]
+    y = torch.full((Bn, Ho, Wo, cout + 16), -3.0, dtype=torch.bfloat16, device=gpu_device)
+    xd = x.to(gpu_device)
+    L.check(L.LIB.yamd_stem_conv(layer.mode, xd.data_ptr(), Bn, H, W, layer.w_dev.data_ptr(), layer.b_dev.data_ptr(), cout, act,
+                                 y.data_ptr() + 8 * 2, y.shape[-1], L.current_stream()), "stem")
+    torch.cuda.synchronize()
+    yc = y.cpu().float()
+    assert torch.all(yc[..., :8] == -3.0) and torch.all(yc[..., 8 + cout:] == -3.0)
+    got = yc[..., 8:8 + cout].permute(0, 3, 1, 2)
+    err = (got - want).abs()
+    tol = 2e-2 + 1e-2 * want.abs()          # bf16 output rounding
+    assert (err <= tol).all(), f"max err {err.max()} at {want.flatten()[err.argmax()]}"

@@ -7,6 +7,7 @@ wider buffer" and costs nothing.  All arithmetic happens inside libyolo_amd.so; 
 device memory and the stream.
 """
 import ctypes
+import os
 from typing import Dict, List, NamedTuple, Optional, Tuple
 
 import torch
@@ -70,12 +71,41 @@ class ConvLayer:
             self.b_dev = self.b_host.to(device)
 
 
+class StemLayer:
+    """First conv of a network, computed straight from the fp32 NCHW image (``yamd_stem_conv``)."""
+
+    MODES = {"k3s1": 0, "k3s2": 1, "focus": 2}
+
+    def __init__(self, name: str, mode: str, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int):
+        w = weight.detach().to(torch.float32).cpu().contiguous()
+        cout, cin_real, k, _ = w.shape
+        assert k == 3 and cin_real == (12 if mode == "focus" else 3)
+        self.name, self.mode, self.act, self.cout, self.cin_real = name, self.MODES[mode], act, cout, cin_real
+        self.macs_per_pixel = cout * cin_real * 9
+        b = None if bias is None else bias.detach().to(torch.float32).cpu().contiguous()
+        n = LIB.yamd_stem_packed_elems(self.mode, cout)
+        if n <= 0:
+            raise _lib.YamdError(f"stem[{name}]: cout={cout} not supported")
+        self.w_host = torch.empty(n, dtype=torch.int16)
+        self.b_host = torch.empty(64, dtype=torch.float32)
+        _lib.check(LIB.yamd_stem_pack_weights(self.mode, w.data_ptr(), None if b is None else b.data_ptr(), cout,
+                                              self.w_host.data_ptr(), self.b_host.data_ptr()), f"stem_pack_weights[{name}]")
+        self.w_dev: Optional[torch.Tensor] = None
+        self.b_dev: Optional[torch.Tensor] = None
+
+    def to(self, device) -> None:
+        if self.w_dev is None or self.w_dev.device != torch.device(device):
+            self.w_dev = self.w_host.to(device)
+            self.b_dev = self.b_host.to(device)
+
+
 class Program:
     def __init__(self, img_h: int, img_w: int):
         self.img_h, self.img_w = img_h, img_w
         self.buffers: Dict[str, Tuple[int, int, int, torch.dtype]] = {}
         self.ops: List[tuple] = []
         self.convs: List[ConvLayer] = []
+        self.stems: List[StemLayer] = []
         self.outputs: Dict[str, View] = {}
         self.alias: Dict[str, Tuple[str, int]] = {}     # buffer -> (wider buffer it lives in, first channel)
         self._alloc: Dict[Tuple[int, str], Dict[str, torch.Tensor]] = {}
@@ -110,6 +140,20 @@ class Program:
         pad = k // 2
         ho = (x.h + 2 * pad - k) // stride + 1
         wo = (x.w + 2 * pad - k) // stride + 1
+        if (x.buf in ("focus", "image16") and self.ops and self.ops[-1][0] in ("focus", "nhwc16") and self.ops[-1][1].buf == x.buf
+                and k == 3 and cout <= 64 and cout % 8 == 0 and residual is None and out2 is None and not out_f32
+                and (x.buf == "image16" or stride == 1) and not os.environ.get("YAMD_NO_STEM")):
+            # the network's first conv reads the image itself: no packed copy of the image is written
+            self.ops.pop()
+            del self.buffers[x.buf]
+            mode = "focus" if x.buf == "focus" else ("k3s1" if stride == 1 else "k3s2")
+            layer = StemLayer(name, mode, weight, bias, act)
+            if out is None:
+                out = self.buffer(ho, wo, cout)
+            assert (out.h, out.w, out.c) == (ho, wo, cout), (name, out, ho, wo, cout)
+            self.stems.append(layer)
+            self.ops.append(("stem", layer, out))
+            return out
         from . import tuning
         layer = ConvLayer(name, weight, bias, stride, act, x.c, out_f32,
                           None if out_f32 else tuning.lookup(k, stride, x.c, cout, ho, wo))
@@ -267,6 +311,8 @@ class Program:
         for op in self.ops:
             if op[0] == "conv":
                 total += op[1].macs_per_pixel * op[3].h * op[3].w
+            elif op[0] == "stem":
+                total += op[1].macs_per_pixel * op[2].h * op[2].w
         return total
 
     def activation_bytes_per_image(self) -> int:
@@ -287,6 +333,10 @@ class Program:
             if res is not None:
                 byts += px * out.c * 2
             return flops, float(byts)
+        if kind == "stem":
+            _, layer, out = op
+            px = batch * out.h * out.w
+            return 2.0 * layer.macs_per_pixel * px, float(batch * self.img_h * self.img_w * 3 * 4 + px * out.c * 2)
         if kind == "focus":
             return 0.0, float(batch * self.img_h * self.img_w * 3 * 4 + batch * op[1].h * op[1].w * 16 * 2)
         if kind == "nhwc16":
@@ -310,7 +360,7 @@ class Program:
             self._alloc.clear()   # one live batch size at a time: the arena is large
             self._alloc[key] = {n: torch.empty((batch, h, w, c), dtype=dt, device=device)
                                 for n, (h, w, c, dt) in self.buffers.items() if n not in self.alias}
-            for layer in self.convs:
+            for layer in self.convs + self.stems:
                 layer.to(device)
         return self._alloc[key]
 
@@ -350,6 +400,11 @@ class Program:
                     _lib.check(LIB.yamd_conv2d_bias_act(ctypes.byref(layer.desc), xp, xcs, layer.w_dev.data_ptr(),
                                                         layer.b_dev.data_ptr(), rp, rcs, yp, ycs, B, x.h, x.w, st),
                                f"conv[{layer.name}]")
+            elif kind == "stem":
+                _, layer, out = op
+                yp, ycs = P(bufs, out)
+                _lib.check(LIB.yamd_stem_conv(layer.mode, images.data_ptr(), B, H, W, layer.w_dev.data_ptr(),
+                                              layer.b_dev.data_ptr(), layer.cout, layer.act, yp, ycs, st), f"stem[{layer.name}]")
             elif kind == "focus":
                 yp, ycs = P(bufs, op[1])
                 _lib.check(LIB.yamd_focus_pack(images.data_ptr(), yp, ycs, B, H, W, st), "focus")
@@ -389,7 +444,10 @@ class Program:
             if timings is not None:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
-                timings.append((kind, op[1].name if kind == "conv" else kind, ev0, ev1) + self.op_cost(op, B))
+                if kind == "stem":          # reported with the convs: it is the first conv layer
+                    timings.append(("conv", op[1].name, ev0, ev1) + self.op_cost(op, B))
+                else:
+                    timings.append((kind, op[1].name if kind == "conv" else kind, ev0, ev1) + self.op_cost(op, B))
         res = {}
         for name, v in self.outputs.items():
             buf, coff = self.resolve(v)
