@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--model", default="v5s", help="model family (yolo_amd.models.registry); v5s is the headline config")
-    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the BASELINE config of the model)")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the benchmark configuration of the model)")
     ap.add_argument("--weights", default="torch_default", choices=["torch_default", "spread"],
                     help="seeded random-init scheme (torch_default = the reference's YoloV5(param) distribution)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -82,9 +82,9 @@ def max_over_ranks(value: float, world: int, dry: bool) -> float:
     return float(t.item())
 
 
-# per-GPU batch of the BASELINE configurations (v8s: 1024 images over 8 GPUs)
+# per-GPU batch of the benchmark configurations (v8s: 1024 images over 8 GPUs)
 DEFAULT_BATCH = {"v5s": 256, "v8s": 128, "v7pose": 512, "v6face": 512, "v3": 256, "v4": 256,
-                 # variants outside the BASELINE configurations: the batch of the nearest configuration
+                 # variants outside the benchmark configurations: the batch of the nearest configuration
                  "v5face": 256, "v5pose": 256, "v7": 256, "v7face": 256, "v6": 256, "v6pose": 256}
 LABEL = {"v5s": "YOLOv5s VOC-20 detect", "v8s": "YOLOv8s VOC-20 detect", "v7pose": "YOLOv7-l pose (17 keypoints)",
          "v6face": "YOLOv6-s face (5 landmarks, 4 levels)", "v3": "YOLOv3 VOC-20 detect", "v4": "YOLOv4 VOC-20 detect",

@@ -52,7 +52,7 @@ def _match_rows_abs(got, want, tol):
 def _model(name, size, seed):
     from yolo_amd import models
     from yolo_amd.init import seeded_state_dict
-    p, m = models.create(name, size)          # size 0: the model's BASELINE image size
+    p, m = models.create(name, size)          # size 0: the model's benchmark image size
     sd = seeded_state_dict(m, seed=seed, mode="spread", **models.init_options(name))
     m.load_state_dict(sd, strict=True)
     return p, m, sd
@@ -169,13 +169,13 @@ def test_yolo_predict_entry_points(gpu_device, tmp_path):
         assert (a is None and b is None) or np.array_equal(a, b.cpu().numpy())
 
 
-FULL = {"v8s": 128, "v3": 256, "v4": 256, "v7pose": 512, "v6face": 512,     # BASELINE per-GPU batch sizes
+FULL = {"v8s": 128, "v3": 256, "v4": 256, "v7pose": 512, "v6face": 512,     # benchmark per-GPU batch sizes
         "v5face": 256, "v5pose": 256, "v7": 256, "v7face": 256, "v6": 256, "v6pose": 256}               # (variants: the v5s batch)
 
 
 @pytest.mark.parametrize("name", NAMES)
 def test_full_batch_properties(name, gpu_device):
-    """BASELINE image size and per-GPU batch: size-independent properties of the whole path -- the position in the
+    """Benchmark image size and per-GPU batch: size-independent properties of the whole path -- the position in the
     batch does not matter (replicated images give bit-identical rows), rows come in descending score order, and
     the kept rows of two images equal the C oracle's NMS of the same decoded tensor bit for bit."""
     from oracle import graphs_ref, postprocess as pp
