@@ -785,15 +785,28 @@ __global__ __launch_bounds__(256) void nms_rows_kernel(NmsParams p)
     if (rbase >= nout) return;
     const int tid = threadIdx.x;
     const int sub = tid & 31, grp = tid >> 5;
+    // inputs and outputs never overlap: with that known, the loads of all four rows of a lane group are issued before
+    // the first store, so the group pays the key -> row dependency once, not four times
+    const float *__restrict__ pred = p.pred;
+    float *__restrict__ out_rows = p.out_rows;
+    constexpr int NIT = ROWS_PER_BLOCK / 8;
+    u32 idxs[NIT];
+    float heads[NIT];
 #pragma unroll
-    for (int it = 0; it < ROWS_PER_BLOCK / 8; ++it) {
+    for (int it = 0; it < NIT; ++it) {
+        const u32 r = rbase + it * 8 + grp;
+        idxs[it] = 0xFFFFFFFFu - (u32)p.bkey[b * p.A + (r < nout ? r : rbase)];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) heads[it] = (sub < 5) ? pred[(b * p.A + idxs[it]) * (long long)p.C + sub] : 0.0f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
         const u32 r = rbase + it * 8 + grp;
         const bool have = r < nout;                                    // uniform in the 32-lane group
-        const u64 key = p.bkey[b * p.A + (have ? r : rbase)];
-        const u32 idx = 0xFFFFFFFFu - (u32)key;
-        const float *row = p.pred + (b * p.A + idx) * (long long)p.C;
-        float *o = p.out_rows + (b * p.max_out + r) * (long long)p.W;
-        const float head = (sub < 5) ? row[sub] : 0.0f;
+        const u32 idx = idxs[it];
+        const float *row = pred + (b * p.A + idx) * (long long)p.C;
+        float *o = out_rows + (b * p.max_out + r) * (long long)p.W;
+        const float head = heads[it];
         const float c0 = __shfl(head, 0, 32), c1 = __shfl(head, 1, 32), c2 = __shfl(head, 2, 32), c3 = __shfl(head, 3, 32);
         const float obj = __shfl(head, 4, 32);
         // first maximum over the classes: strided per lane, then across lanes (ties: smaller index); a NaN only
