@@ -7,7 +7,8 @@ import json
 import os
 from typing import Dict, List, Optional, Tuple
 
-PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
+# YAMD_TUNING_TABLE: another table file (A/B runs); YAMD_NO_TUNING: the built-in rule for every layer
+PATH = os.environ.get("YAMD_TUNING_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gfx950.json")
 _table: Optional[Dict[str, List[int]]] = None
 enabled = os.environ.get("YAMD_NO_TUNING", "") == ""
 
@@ -64,6 +65,7 @@ def main() -> None:
     ap.add_argument("--model", default="v5s")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--out", default=PATH)
+    ap.add_argument("--reps", type=int, default=10, help="timed launches per candidate")
     args = ap.parse_args()
     global enabled
     enabled = False                                    # start every layer from the default rule
@@ -72,7 +74,7 @@ def main() -> None:
     prog = m.program()
     imgs = torch.rand(args.batch, 3, p.img_size, p.img_size, device=dev)
     prog.run(imgs)                                     # fill the buffers with real activations
-    best = prog.autotune(args.batch, dev, log=print)
+    best = prog.autotune(args.batch, dev, reps=args.reps, log=print)
     save(best, args.out)
     print(f"{len(best)} layer shapes -> {args.out}")
 
