@@ -305,6 +305,56 @@ class Program:
                 log(f"{layer.name:34s} {key:28s} " + "  ".join(f"{c}={t:.4f}" for t, c in results[:5]))
         return best
 
+    def autotune_in_situ(self, images: torch.Tensor, reps: int = 7, log=None) -> Dict[str, Tuple[int, ...]]:
+        """Like ``autotune``, but every candidate tiling is timed inside a run of the whole program (events around the
+        layers of that shape), so its inputs come from where the previous layer left them (HBM or L2) and not from a
+        cache warmed by running the same layer back to back.  Starts from the tilings the layers currently have."""
+        import statistics
+        from . import tuning
+        groups: Dict[str, list] = {}
+        for op in self.ops:
+            if op[0] != "conv" or op[1].desc.out_f32:
+                continue
+            _, layer, x, out, res, out2 = op
+            cout = out.c + (out2.c if out2 is not None else 0)
+            k, s = layer._args[0], layer._args[1]
+            groups.setdefault(tuning.key(k, s, x.c, cout, out.h, out.w), []).append((layer, k, s, x.c, cout))
+        device = images.device
+
+        def measure(names) -> float:
+            ts = []
+            for _ in range(reps):
+                t: list = []
+                self.run(images, timings=t)
+                torch.cuda.synchronize()
+                ts.append(sum(e0.elapsed_time(e1) for kind, name, e0, e1, _f, _b in t if kind == "conv" and name in names))
+            return statistics.median(ts)
+
+        best: Dict[str, Tuple[int, ...]] = {}
+        self.run(images)
+        for key, members in groups.items():
+            names = {m[0].name for m in members}
+            _, k, s, cin, cout = members[0]
+            start = members[0][0].tiling
+            results = []
+            for cand in tuning.candidates(k, s, cin, cout):
+                try:
+                    for m in members:
+                        m[0].pack(cand)
+                        m[0].to(device)
+                    self.run(images)
+                except _lib.YamdError:
+                    continue
+                results.append((measure(names), cand))
+            results.sort()
+            best[key] = results[0][1] if results else start
+            for m in members:
+                m[0].pack(best[key])
+                m[0].to(device)
+            if log is not None:
+                log(f"{key:28s} x{len(members)} " + "  ".join(f"{c}={t:.4f}" for t, c in results[:5]))
+        return best
+
     # ---- accounting ------------------------------------------------------------------------------
     def conv_macs_per_image(self) -> int:
         total = 0

@@ -66,15 +66,20 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--out", default=PATH)
     ap.add_argument("--reps", type=int, default=10, help="timed launches per candidate")
+    ap.add_argument("--in-situ", action="store_true", help="time candidates inside whole-program runs (realistic cache state)")
     args = ap.parse_args()
     global enabled
-    enabled = False                                    # start every layer from the default rule
+    if not args.in_situ:
+        enabled = False                                # start every layer from the default rule
     p, m = models.create(args.model)
     dev = torch.device("cuda", 0)
     prog = m.program()
     imgs = torch.rand(args.batch, 3, p.img_size, p.img_size, device=dev)
     prog.run(imgs)                                     # fill the buffers with real activations
-    best = prog.autotune(args.batch, dev, reps=args.reps, log=print)
+    if args.in_situ:
+        best = prog.autotune_in_situ(imgs, reps=args.reps, log=print)
+    else:
+        best = prog.autotune(args.batch, dev, reps=args.reps, log=print)
     save(best, args.out)
     print(f"{len(best)} layer shapes -> {args.out}")
 
