@@ -270,6 +270,9 @@ def _ref_models():
     """name -> (reference class, param factory, raw head order of body_net, row width, small size)"""
     return {
         "v8s": (YoloV8, lambda: Yolo8Param(m_type="s"), "asc", 7, 64),
+        "v8m": (YoloV8, lambda: Yolo8Param(m_type="m"), "asc", 7, 64),
+        "v8n": (YoloV8, lambda: Yolo8Param(m_type="n"), "asc", 7, 64),
+        "v5m": (_lazy("luoyang.yolov5.YoloV5", "YoloV5"), lambda: _lazy("luoyang.param.Param", "Yolo5Param")(m_type="m"), "desc", 7, 64),
         "v3": (YoloV3, lambda: Yolo3Param(), "desc", 7, 64),
         "v4": (YoloV4, lambda: Yolo4Param(), "desc", 7, 64),
         "v7pose": (YoloV7Pose, lambda: Yolo7PoseParam(m_type="l"), "desc", 6 + 3 * 17 + 1, 64),

@@ -363,11 +363,11 @@ def model_ref(name: str):
     """dict(body=fn(sd, images)->raws NCHW ascending stride, decode=fn(raws_np, param, predict)->(B,A,C),
     nms=kwargs of oracle.postprocess.non_max_suppression used by the reference's predict())."""
     from oracle import decode_ref, v5_ref
-    if name == "v5s":
+    if name in ("v5s", "v5m"):
         return dict(body=v5_ref.body_forward,
                     decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "v5"),
                     nms=dict(in_fmt="cxcywh"))
-    if name == "v8s":
+    if name in ("v8s", "v8m", "v8n"):
         return dict(body=v8_body,
                     decode=lambda raws, p, predict: decode_ref.decode_dfl(raws, p.strides, 16, p.class_num,
                                                                           "xyxy" if predict else "cxcywh"),

@@ -125,7 +125,7 @@ def test_checkpoint_architecture_detection(tmp_path):
     import torch
     from yolo_amd import models
     from yolo_amd.init import seeded_state_dict
-    for name in ("v5s", "v8s", "v4", "v7pose", "v6face", "v5face", "v5pose", "v7", "v7face", "v6", "v6pose"):
+    for name in ("v5s", "v8s", "v4", "v7pose", "v6face", "v5face", "v5pose", "v7", "v7face", "v6", "v6pose", "v5m", "v8m", "v8n"):
         size = 128 if name in ("v6face", "v6", "v6pose") else 64
         p, m = models.create(name, size)
         sd = seeded_state_dict(m, seed=2, mode="spread", **models.init_options(name))

@@ -91,6 +91,15 @@ CONV_CASES = [
     (3, 2, 64, 128, 40, 40, 1, False, False),
     (3, 2, 128, 256, 23, 31, 4, False, False),
     (3, 2, 256, 512, 40, 40, 1, False, False),
+    # input widths that are multiples of 16 but not of 32 (m-size networks): 16-channel chunks
+    (1, 1, 48, 48, 20, 20, 1, True, False),
+    (1, 1, 48, 96, 17, 23, 1, False, False),
+    (1, 1, 144, 160, 20, 20, 1, False, False),
+    (3, 1, 48, 48, 24, 24, 1, True, False),
+    (3, 1, 80, 80, 20, 20, 1, False, False),
+    (3, 2, 48, 96, 32, 32, 1, False, False),
+    (1, 1, 80, 75, 20, 20, 0, False, True),
+    (1, 1, 96, 75, 16, 16, 0, False, True),
 ]
 
 

@@ -28,18 +28,23 @@ extern "C" int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int
     d->mrep = (stride == 2) ? 1 : 2;
     d->nwaves = 4;
     if (out_f32) {
-        YAMD_REQUIRE(ksize == 1 && cin % 64 == 0, "float output is only built for 1x1 convs with cin %% 64 == 0");
+        YAMD_REQUIRE(ksize == 1, "float output is only built for 1x1 convs");
         d->nrep = 4;
-        d->ck = 64;
+        d->ck = cin % 64 == 0 ? 64 : (cin % 32 == 0 ? 32 : 16);
     } else if (ksize == 1) {
-        d->nrep = groups >= 4 ? 4 : (groups >= 2 ? 2 : 1);
-        d->ck = (cin % 64 == 0) ? 64 : 32;
-        YAMD_REQUIRE(cin % 32 == 0, "1x1 conv needs cin %% 32 == 0 (got %d)", cin);
+        YAMD_REQUIRE(cin % 16 == 0, "1x1 conv needs cin %% 16 == 0 (got %d)", cin);
+        if (cin % 32 == 0) {
+            d->nrep = groups >= 4 ? 4 : (groups >= 2 ? 2 : 1);
+            d->ck = (cin % 64 == 0) ? 64 : 32;
+        } else {                      // e.g. 48 channels: 16-channel chunks
+            d->nrep = groups >= 4 ? 4 : 1;
+            d->ck = 16;
+        }
     } else if (stride == 1) {
-        if (cin % 32 != 0) {          // 16-channel stem
+        if (cin % 32 != 0) {          // 16-channel stem, 48-channel layers ...: 16-channel chunks
+            YAMD_REQUIRE(cin % 16 == 0, "3x3 conv needs cin %% 16 == 0 (got %d)", cin);
             d->ck = 16;
             d->nrep = groups >= 4 ? 4 : 1;
-            YAMD_REQUIRE(groups == 1 || groups >= 4, "3x3 conv with cin=%d cout=%d not built", cin, cout);
         } else if (groups >= 4) {
             d->ck = 16;
             d->nrep = 4;
@@ -75,7 +80,7 @@ extern "C" int yamd_conv_desc_tune(yamd_conv_desc *d, int mrep, int nrep, int ck
     YAMD_REQUIRE(!d->out_f32, "the float-output kernel has one tiling");
     bool built;
     if (d->ksize == 1) {
-        built = ck >= 32;
+        built = ck >= 32 || (ck == 16 && mrep == 2 && (nrep == 1 || nrep == 4) && nwaves == 4);
         if (nwaves == 8)
             built = (nrep == 4 && ck == 64) || (mrep == 1 && nrep == 4 && ck == 32) || (nrep == 2 && ck == 64);
     } else if (d->stride == 1) {

@@ -21,6 +21,13 @@ def registry() -> Dict[str, Dict[str, Any]]:
         "v5pose": dict(cls=YoloV5Pose, param=lambda: _param.Yolo5PoseParam(m_type="s"), init=dict(scale={"yolo_head_P": 0.1})),
         "v5s": dict(cls=YoloV5, param=lambda: _param.Yolo5Param(m_type="s").set_img_size(640), init={}),
         "v8s": dict(cls=YoloV8, param=lambda: _param.Yolo8Param(m_type="s"), init={}),
+        # other widths of the two benchmark families (channel counts that are multiples of 16 but not of 32)
+        # 2 / 6 / 6 bottlenecks per C3 with un-normalised residual adds: damp every bottleneck's last BatchNorm so that
+        # random-init logits keep a std near 1 (they reach 20-50 otherwise)
+        "v5m": dict(cls=YoloV5, param=lambda: _param.Yolo5Param(m_type="m").set_img_size(640),
+                    init=dict(scale={f"m.{i}.cv2.bn.weight": 0.5 for i in range(6)})),
+        "v8m": dict(cls=YoloV8, param=lambda: _param.Yolo8Param(m_type="m"), init={}),
+        "v8n": dict(cls=YoloV8, param=lambda: _param.Yolo8Param(m_type="n"), init={}),
         # 23 un-normalised residual adds: damp the branch output so random-init activations stay in range, and the
         # head convs so that the logits (w,h go through exp) have a std of 1-2
         "v3": dict(cls=YoloV3, param=lambda: _param.Yolo3Param().set_img_size(608),
