@@ -277,6 +277,7 @@ def _ref_models():
         "v4": (YoloV4, lambda: Yolo4Param(), "desc", 7, 64),
         "v7pose": (YoloV7Pose, lambda: Yolo7PoseParam(m_type="l"), "desc", 6 + 3 * 17 + 1, 64),
         "v6face": (YoloV6Face, lambda: Yolo6FaceParam(m_type="s"), "v6", 6 + 2 * 5 + 1, 128),
+        "v6facen": (YoloV6Face, lambda: Yolo6FaceParam(m_type="n"), "v6", 6 + 2 * 5 + 1, 128),
         "v6": (_lazy("luoyang.yolov6.YoloV6", "YoloV6"), lambda: _lazy("luoyang.param.Param", "Yolo6Param")(m_type="s"), "v6", 7, 128),
         "v6pose": (_lazy("luoyang.yolov6_pose.YoloV6Pose", "YoloV6Pose"), lambda: _lazy("luoyang.param.Param", "Yolo6PoseParam")(m_type="s"),
                    "v6", 6 + 3 * 17 + 1, 128),

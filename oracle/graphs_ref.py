@@ -411,7 +411,7 @@ def model_ref(name: str):
                                                                                   p.class_num + p.point_num,
                                                                                   "xyxy" if predict else "cxcywh"),
                     nms=dict(in_fmt="xyxy", point_num=17, point_conf=True))
-    if name == "v6face":
+    if name in ("v6face", "v6facen"):
         return dict(body=v6face_body,
                     decode=lambda raws, p, predict: decode_ref.decode_ltrb_points(raws, p.strides, p.point_num, p.class_num,
                                                                                   "xyxy" if predict else "cxcywh"),

@@ -51,6 +51,10 @@ def registry() -> Dict[str, Dict[str, Any]]:
                        init=dict(scale={".rbr_dense.bn.weight": 0.55, ".rbr_1x1.bn.weight": 0.55,
                                         ".rbr_identity.weight": 0.55, "reg_predict_list": 0.3,
                                         "reg_point_predict_list": 0.3})),
+        "v6facen": dict(cls=YoloV6Face, param=lambda: _param.Yolo6FaceParam(m_type="n"),
+                       init=dict(scale={".rbr_dense.bn.weight": 0.55, ".rbr_1x1.bn.weight": 0.55,
+                                        ".rbr_identity.weight": 0.55, "reg_predict_list": 0.3,
+                                        "reg_point_predict_list": 0.3})),
     }
 
 
