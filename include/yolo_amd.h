@@ -58,7 +58,8 @@ typedef struct yamd_conv_desc {
     int32_t nrep, ck, mrep, cout_pad;
     int64_t packed_w_elems;   /* bf16 elements of the packed weight blob */
     int32_t nwaves;           /* 4 or 8 wavefronts per workgroup (they share one staged weight tile) */
-    int32_t reserved;
+    float residual_scale;     /* y = act(..) + residual_scale * residual; yamd_conv_desc_init sets 1 (the learned
+                               * shortcut weight ``alpha`` of BottleRep, yolov6/YoloV6Body.py:451-472) */
 } yamd_conv_desc;
 
 int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int cin, int cout, int act, int out_f32);
@@ -154,6 +155,13 @@ int yamd_decode_anchor(int kind, const float *raw, int batch, int h, int w, int 
 int yamd_decode_dfl(const float *const *raw_host_ptrs, const int *hs_host, const int *ws_host,
                     const int *strides_host, int n_levels, int batch, int reg_max, int nc, int out_cxcywh,
                     float *out, void *stream);
+/* The DFL decode of YOLOv6 m/l (yolov6/YoloV6Body.py:1322-1343 bbox_decode with use_dfl, :1345-1380; assembled by
+ * yolov6/YoloV6.py:41-55 and :62-74): ``bins`` = reg_max + 1 logits per box side whose softmax is projected on
+ * 0..reg_max; column 4 of ``out`` is the constant 1.0 the reference puts in place of an objectness.  Otherwise as
+ * yamd_decode_dfl. */
+int yamd_decode_dfl_unit_conf(const float *const *raw_host_ptrs, const int *hs_host, const int *ws_host,
+                              const int *strides_host, int n_levels, int batch, int bins, int nc, int out_cxcywh,
+                              float *out, void *stream);
 
 /* Anchor-free decode without DFL plus landmarks, all levels in one call (yolov6_face/YoloV6FaceBody.py:1354-1397
  * bbox_decode/point_decode and :1439-1455, assembled by yolov6_face/YoloV6Face.py:42-58 and :60-74).

@@ -108,9 +108,11 @@ def decode_anchor(raws: List[np.ndarray], anchors: Sequence[Tuple[int, int]], st
 
 
 def decode_dfl(raws: List[np.ndarray], strides: Sequence[int], reg_max: int, num_classes: int,
-               out_fmt: str) -> np.ndarray:
+               out_fmt: str, unit_conf: bool = False) -> np.ndarray:
     """v8: raws[i] (B, 4*reg_max+nc, H, W) -> (B, A, 4+1+nc): [box, max-class conf, class scores];
-    box is xyxy (predict form) or cxcywh (_forward form), input pixels."""
+    box is xyxy (predict form) or cxcywh (_forward form), input pixels.
+    v6 m/l (luoyang/yolov6/YoloV6Body.py:1322-1343 and :1345-1380, luoyang/yolov6/YoloV6.py:41-74): the same with
+    reg_max = 17 bins and ``unit_conf``: the confidence column is the constant 1."""
     B = raws[0].shape[0]
     flat = np.concatenate([r.reshape(B, r.shape[1], -1) for r in raws], axis=2).astype(F32)
     dist, cls = flat[:, :4 * reg_max], flat[:, 4 * reg_max:]
@@ -140,7 +142,7 @@ def decode_dfl(raws: List[np.ndarray], strides: Sequence[int], reg_max: int, num
         wh = box[..., 2:] - box[..., :2]
         box = np.concatenate((cxy, wh), -1)
     sc = _sigmoid(cls)
-    conf = sc.max(axis=-1, keepdims=True)
+    conf = np.ones_like(sc[..., :1]) if unit_conf else sc.max(axis=-1, keepdims=True)
     return np.concatenate((box, conf, sc), -1).astype(F32)
 
 

@@ -299,15 +299,51 @@ def _v6_bifusion(sd, p, xs):
     return _v6_w(sd, p + ".cv3", torch.cat((x0, x1, x2), 1))
 
 
+# YOLOv6 detect m/l: luoyang/yolov6/YoloV6Body.py BottleRep.forward :468-472 (outputs + alpha * x), RepBlock :427-449
+# (conv1 + block of BottleReps), BepC3.forward :738-739, SPPFModule.forward :333-337 under SimSPPF (``spp_f``, ReLU) or
+# SPPF (``sppf``, SiLU), CSPBepBackboneP6.forward :892-906, CSPRepBiFPANNeckP6.forward :1000-1022; the basic block is
+# RepVGGBlock (m) or ConvBNSiLU (l), and BepC3's own 1x1 convs follow it (ReLU / SiLU), :1185-1188, :730-736
+def _v6_basic(sd, p, x, s=1):
+    return _v6_rep(sd, p, x, s) if _v6_is_rep(sd, p) else _v6_w(sd, p, x, s, silu)
+
+
+def _v6_bottle_rep(sd, p, x):
+    return _v6_basic(sd, p + ".conv2", _v6_basic(sd, p + ".conv1", x)) + sd[p + ".alpha"] * x
+
+
+def _v6_bepc3(sd, p, x, act):
+    y = _v6_bottle_rep(sd, p + ".m.conv1", _v6_w(sd, p + ".cv1", x, 1, act))
+    i = 0
+    while f"{p}.m.block.{i}.alpha" in sd:
+        y = _v6_bottle_rep(sd, f"{p}.m.block.{i}", y)
+        i += 1
+    return _v6_w(sd, p + ".cv3", torch.cat((y, _v6_w(sd, p + ".cv2", x, 1, act)), 1), 1, act)
+
+
 def v6face_body(sd: SD, images: torch.Tensor) -> List[torch.Tensor]:
     """images (B,3,S,S) -> per level (stride 8, 16, 32, 64) raw head logits (B, 4+2P+nc, h, w) in the channel
-    order [ltrb | landmarks | cls]."""
+    order [ltrb | landmarks | cls] (detect m/l: [4 x 17 DFL logits | cls])."""
     b, n, h = "yolo_body.back_bone_network.", "yolo_body.neck_network.", "yolo_body.head."
-    x = _v6_rep(sd, b + "stem", images, 2)
+    csp = f"{b}ERBlock_2.1.cv3.block.conv.weight" in sd
+    csp_act = F.relu if _v6_is_rep(sd, b + "stem") else silu
+
+    def stage(sd, p, x):
+        return _v6_bepc3(sd, p, x, csp_act) if csp else _v6_repblock(sd, p, x)
+
+    def fusion(sd, p, xs):
+        return _v6_bifusion(sd, p.replace("Bi_fusion", "bi_fusion") if csp else p, xs)
+    x = _v6_basic(sd, b + "stem", images, 2)
     feats = []
     for i in range(2, 7):
-        x = _v6_repblock(sd, f"{b}ERBlock_{i}.1", _v6_rep(sd, f"{b}ERBlock_{i}.0", x, 2))
-        if i == 6:
+        x = stage(sd, f"{b}ERBlock_{i}.1", _v6_basic(sd, f"{b}ERBlock_{i}.0", x, 2))
+        if i == 6 and csp:
+            sp, a = (f"{b}ERBlock_6.2.spp_f", F.relu) if f"{b}ERBlock_6.2.spp_f.cv1.block.conv.weight" in sd else \
+                (f"{b}ERBlock_6.2.sppf", silu)
+            x1 = _v6_w(sd, sp + ".cv1", x, 1, a)
+            y1 = F.max_pool2d(x1, 5, 1, 2)
+            y2 = F.max_pool2d(y1, 5, 1, 2)
+            x = _v6_w(sd, sp + ".cv2", torch.cat((x1, y1, y2, F.max_pool2d(y2, 5, 1, 2)), 1), 1, a)
+        elif i == 6:
             sp = f"{b}ERBlock_6.2.cspsppf"
             x1 = _v6_w(sd, sp + ".cv4", _v6_w(sd, sp + ".cv3", _v6_w(sd, sp + ".cv1", x)))
             y0 = _v6_w(sd, sp + ".cv2", x)
@@ -318,14 +354,14 @@ def v6face_body(sd: SD, images: torch.Tensor) -> List[torch.Tensor]:
         feats.append(x)
     x4, x3, x2, x1, x0 = feats
     fpn0 = _v6_w(sd, n + "reduce_layer0", x0)
-    f0 = _v6_repblock(sd, n + "Rep_p5", _v6_bifusion(sd, n + "Bi_fusion_0", [fpn0, x1, x2]))
+    f0 = stage(sd, n + "Rep_p5", fusion(sd, n + "Bi_fusion_0", [fpn0, x1, x2]))
     fpn1 = _v6_w(sd, n + "reduce_layer1", f0)
-    f1 = _v6_repblock(sd, n + "Rep_p4", _v6_bifusion(sd, n + "Bi_fusion_1", [fpn1, x2, x3]))
+    f1 = stage(sd, n + "Rep_p4", fusion(sd, n + "Bi_fusion_1", [fpn1, x2, x3]))
     fpn2 = _v6_w(sd, n + "reduce_layer2", f1)
-    pan3 = _v6_repblock(sd, n + "Rep_p3", _v6_bifusion(sd, n + "Bi_fusion_2", [fpn2, x3, x4]))
-    pan2 = _v6_repblock(sd, n + "Rep_n4", torch.cat((_v6_w(sd, n + "down_sample_2", pan3, 2), fpn2), 1))
-    pan1 = _v6_repblock(sd, n + "Rep_n5", torch.cat((_v6_w(sd, n + "down_sample_1", pan2, 2), fpn1), 1))
-    pan0 = _v6_repblock(sd, n + "Rep_n6", torch.cat((_v6_w(sd, n + "down_sample_0", pan1, 2), fpn0), 1))
+    pan3 = stage(sd, n + "Rep_p3", fusion(sd, n + "Bi_fusion_2", [fpn2, x3, x4]))
+    pan2 = stage(sd, n + "Rep_n4", torch.cat((_v6_w(sd, n + "down_sample_2", pan3, 2), fpn2), 1))
+    pan1 = stage(sd, n + "Rep_n5", torch.cat((_v6_w(sd, n + "down_sample_1", pan2, 2), fpn1), 1))
+    pan0 = stage(sd, n + "Rep_n6", torch.cat((_v6_w(sd, n + "down_sample_0", pan1, 2), fpn0), 1))
     outs = []
     for i, t in enumerate((pan3, pan2, pan1, pan0)):
         if f"{h}stems.{i}.block.conv.weight" not in sd:
@@ -400,6 +436,11 @@ def model_ref(name: str):
                     decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "pose",
                                                                              point_num=p.point_num, clamp_points=predict),
                     nms=dict(in_fmt="cxcywh", point_num=17, point_conf=True))
+    if name in ("v6m", "v6l"):
+        return dict(body=v6face_body,
+                    decode=lambda raws, p, predict: decode_ref.decode_dfl(raws, p.strides, 17, p.class_num,
+                                                                          "xyxy" if predict else "cxcywh", unit_conf=True),
+                    nms=dict(in_fmt="xyxy"))
     if name == "v6":
         return dict(body=v6face_body,
                     decode=lambda raws, p, predict: decode_ref.decode_ltrb_points(raws, p.strides, 0, p.class_num,

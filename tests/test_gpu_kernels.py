@@ -31,7 +31,7 @@ def _act(y, act):
     return y
 
 
-def _run_conv(dev, x, w, b, k, s, act, res=None, out_f32=False, in_extra=0, out_extra=0, tiling=None):
+def _run_conv(dev, x, w, b, k, s, act, res=None, out_f32=False, in_extra=0, out_extra=0, tiling=None, res_scale=None):
     """x (B,Cin,H,W) fp32 (already bf16-representable); returns (B,Cout,Ho,Wo) fp32 from the HIP kernel.
     in_extra/out_extra: additional channels around the tensor inside a wider buffer (cstride test)."""
     from yolo_amd import lib as L
@@ -42,6 +42,9 @@ def _run_conv(dev, x, w, b, k, s, act, res=None, out_f32=False, in_extra=0, out_
     L.check(L.LIB.yamd_conv_desc_init(ctypes.byref(d), k, s, cin_st, cout, act, int(out_f32)))
     if tiling is not None:
         L.check(L.LIB.yamd_conv_desc_tune(ctypes.byref(d), *tiling))
+    assert d.residual_scale == 1.0
+    if res_scale is not None:
+        d.residual_scale = res_scale
     wp = torch.empty(d.packed_w_elems, dtype=torch.int16)
     bp = torch.empty(d.cout_pad, dtype=torch.float32)
     wc, bc = w.contiguous(), b.contiguous()
@@ -124,6 +127,22 @@ def test_conv_parity(gpu_device, k, s, cin, cout, H, W, act, use_res, out_f32):
     tol_l2, tol_abs = (1e-4, 1e-3) if out_f32 else (4e-3, 1.5e-2)
     assert rel_l2 <= tol_l2, f"rel L2 {rel_l2}"
     assert max_abs <= tol_abs * float(want.abs().max()), f"max abs {max_abs} vs {float(want.abs().max())}"
+
+
+@pytest.mark.parametrize("k,cin,cout,H,W,act,alpha", [(3, 64, 64, 20, 20, 4, 0.6), (3, 128, 128, 17, 23, 1, -1.25),
+                                                       (1, 96, 96, 40, 40, 4, 0.0)])
+def test_conv_weighted_residual(gpu_device, k, cin, cout, H, W, act, alpha):
+    """y = act(conv(x)) + alpha * residual: the learned shortcut weight of YOLOv6's BottleRep."""
+    g = torch.Generator().manual_seed(77 + cin + H)
+    x = _bf16_round(torch.randn((2, cin, H, W), generator=g))
+    w = _bf16_round(torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+    b = torch.randn((cout,), generator=g) * 0.5
+    res = _bf16_round(torch.randn((2, cout, H, W), generator=g))
+    want = _act(F.conv2d(x, w, b, padding=k // 2), act) + alpha * res
+    got = _run_conv(gpu_device, x, w, b, k, 1, act, res, res_scale=alpha)
+    err = (got - want).double()
+    assert float(err.norm() / want.double().norm()) <= 4e-3
+    assert float(err.abs().max()) <= 1.5e-2 * float(want.abs().max())
 
 
 TILING_CASES = [

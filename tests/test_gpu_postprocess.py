@@ -40,6 +40,21 @@ def test_decode_anchor_kinds_vs_golden(gpu_device):
         np.testing.assert_allclose(got, G[f"face_head{i}"], rtol=RTOL, atol=ATOL)
 
 
+def test_decode_dfl_17_bins_unit_conf(gpu_device):
+    """The YOLOv6 m/l form: 17 bins per side, four levels, confidence column 1.0; against the CPU restatement."""
+    from oracle import decode_ref as D
+    from yolo_amd import torch_utils as tu
+    rng = np.random.RandomState(5)
+    nc, strides, sizes = 20, [8, 16, 32, 64], [(16, 24), (8, 12), (4, 6), (2, 3)]
+    raws = [(rng.standard_normal((3, 68 + nc, h, w)) * 2.5).astype(np.float32) for h, w in sizes]
+    dev = [torch.from_numpy(np.ascontiguousarray(r.transpose(0, 2, 3, 1))).to(gpu_device) for r in raws]
+    for fmt in ("cxcywh", "xyxy"):
+        want = D.decode_dfl(raws, strides, 17, nc, fmt, unit_conf=True)
+        got = tu.decode_dfl(dev, strides, 17, nc, fmt, unit_conf=True).cpu().numpy()
+        assert (got[..., 4] == 1.0).all()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-4)
+
+
 def test_decode_dfl_vs_golden(gpu_device):
     from yolo_amd import torch_utils as tu
     G = load_golden("decode.npz")

@@ -27,6 +27,7 @@ extern "C" int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int
     const int groups = (cout + 31) / 32;
     d->mrep = (stride == 2) ? 1 : 2;
     d->nwaves = 4;
+    d->residual_scale = 1.0f;
     if (out_f32) {
         YAMD_REQUIRE(ksize == 1, "float output is only built for 1x1 convs");
         d->nrep = 4;
@@ -200,6 +201,7 @@ int conv_impl(const yamd_conv_desc *d, const void *x, int x_cstride, const void 
     p.split = split;
     p.x_cs = x_cstride;
     p.res_cs = res_cstride;
+    p.res_scale = d->residual_scale;
     p.y_cs = y_cstride;
     p.H = h;
     p.W = w;

@@ -41,6 +41,7 @@ struct ConvParams {
     int TH, tiles_x, tiles_y, n_tiles, nchunks;
     int act;
     int total_tiles;
+    float res_scale;             // weight of the residual in the sum
 #ifdef YAMD_CONV_TRACE
     unsigned long long *trace;   // 8 timestamps per workgroup (profiling builds only)
 #endif
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_kernel(Co
                     act4<ACT>(v);
                     if (has_res) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float)rr[n][i][j];
+                        for (int j = 0; j < 4; ++j) v[j] += p.res_scale * (float)rr[n][i][j];
                     }
                     bf16x4 o;
 #pragma unroll

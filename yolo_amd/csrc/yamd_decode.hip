@@ -108,6 +108,7 @@ struct DflParams {
     const float *raw;
     float *out;
     int H, W, reg_max, nc, stride, out_cxcywh;
+    int unit_conf;                         // column 4 is the constant 1 instead of the best class score
     long long rows_per_image, row_offset;
 };
 
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void decode_dfl_kernel(DflParams p)
         }
         float best = o[5];
         for (int c = 1; c < p.nc; ++c) best = fmaxf(best, o[5 + c]);
-        o[4] = best;
+        o[4] = p.unit_conf ? 1.0f : best;
     }
     __syncthreads();
     float *dst = p.out + (b * p.rows_per_image + p.row_offset + p0) * (long long)CO;
@@ -275,8 +276,9 @@ extern "C" int yamd_decode_anchor(int kind, const float *raw, int batch, int h, 
     return YAMD_OK;
 }
 
-extern "C" int yamd_decode_dfl(const float *const *raw_host_ptrs, const int *hs, const int *ws, const int *strides,
-                               int n_levels, int batch, int reg_max, int nc, int out_cxcywh, float *out, void *stream)
+static int decode_dfl_impl(const float *const *raw_host_ptrs, const int *hs, const int *ws, const int *strides,
+                           int n_levels, int batch, int reg_max, int nc, int out_cxcywh, int unit_conf, float *out,
+                           void *stream)
 {
     YAMD_REQUIRE(raw_host_ptrs && hs && ws && strides && out, "null argument");
     YAMD_REQUIRE(n_levels > 0 && n_levels <= 8 && batch > 0 && batch <= 65535 && reg_max > 0 && nc > 0, "bad shape");
@@ -296,6 +298,7 @@ extern "C" int yamd_decode_dfl(const float *const *raw_host_ptrs, const int *hs,
         p.nc = nc;
         p.stride = strides[i];
         p.out_cxcywh = out_cxcywh ? 1 : 0;
+        p.unit_conf = unit_conf;
         p.rows_per_image = rows;
         p.row_offset = off;
         hipLaunchKernelGGL(decode_dfl_kernel, dim3(ceil_div((long long)hs[i] * ws[i], DPIX), batch), dim3(256), lds,
@@ -304,6 +307,19 @@ extern "C" int yamd_decode_dfl(const float *const *raw_host_ptrs, const int *hs,
         off += (long long)hs[i] * ws[i];
     }
     return YAMD_OK;
+}
+
+extern "C" int yamd_decode_dfl(const float *const *raw_host_ptrs, const int *hs, const int *ws, const int *strides,
+                               int n_levels, int batch, int reg_max, int nc, int out_cxcywh, float *out, void *stream)
+{
+    return decode_dfl_impl(raw_host_ptrs, hs, ws, strides, n_levels, batch, reg_max, nc, out_cxcywh, 0, out, stream);
+}
+
+extern "C" int yamd_decode_dfl_unit_conf(const float *const *raw_host_ptrs, const int *hs, const int *ws,
+                                         const int *strides, int n_levels, int batch, int bins, int nc, int out_cxcywh,
+                                         float *out, void *stream)
+{
+    return decode_dfl_impl(raw_host_ptrs, hs, ws, strides, n_levels, batch, bins, nc, out_cxcywh, 1, out, stream);
 }
 
 extern "C" int yamd_decode_ltrb_points(const float *const *raw_host_ptrs, const int *hs, const int *ws, const int *strides,

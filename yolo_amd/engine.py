@@ -33,7 +33,7 @@ class ConvLayer:
     """One fused conv: descriptor + packed weights (host copies kept so any device can be fed)."""
 
     def __init__(self, name: str, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, act: int,
-                 cin_stored: int, out_f32: bool, tiling: Optional[Tuple[int, ...]] = None):
+                 cin_stored: int, out_f32: bool, tiling: Optional[Tuple[int, ...]] = None, residual_scale: float = 1.0):
         w = weight.detach().to(torch.float32).cpu().contiguous()
         cout, cin_real, k, k2 = w.shape
         assert k == k2
@@ -43,6 +43,7 @@ class ConvLayer:
         self._w = w
         self._b = None if bias is None else bias.detach().to(torch.float32).cpu().contiguous()
         self._args = (k, stride, cin_stored, cout, act, int(out_f32))
+        self.residual_scale = float(residual_scale)
         self.pack(tiling)
 
     def pack(self, tiling: Optional[Tuple[int, ...]] = None) -> None:
@@ -52,6 +53,7 @@ class ConvLayer:
         _lib.check(LIB.yamd_conv_desc_init(ctypes.byref(self.desc), *self._args), f"conv_desc_init[{name}]")
         if tiling is not None:
             _lib.check(LIB.yamd_conv_desc_tune(ctypes.byref(self.desc), *tiling), f"conv_desc_tune[{name}]")
+        self.desc.residual_scale = self.residual_scale
         wp = torch.empty(self.desc.packed_w_elems, dtype=torch.int16)
         bp = torch.empty(self.desc.cout_pad, dtype=torch.float32)
         _lib.check(LIB.yamd_conv_pack_weights(ctypes.byref(self.desc), self._w.data_ptr(), self.cin_real,
@@ -132,8 +134,9 @@ class Program:
 
     def conv(self, name: str, x: View, weight: torch.Tensor, bias: Optional[torch.Tensor], stride: int, act: int,
              out: Optional[View] = None, residual: Optional[View] = None, out_f32: bool = False,
-             out2: Optional[View] = None) -> View:
-        """``out2``: the last ``out2.c`` output channels go to that view instead, the first ``cout - out2.c`` to ``out``
+             out2: Optional[View] = None, residual_scale: float = 1.0) -> View:
+        """``residual_scale``: the output is act(conv) + residual_scale * residual.
+        ``out2``: the last ``out2.c`` output channels go to that view instead, the first ``cout - out2.c`` to ``out``
         (one conv computing two branches whose consumers want each branch densely packed)."""
         k = weight.shape[-1]
         cout = weight.shape[0]
@@ -156,7 +159,7 @@ class Program:
             return out
         from . import tuning
         layer = ConvLayer(name, weight, bias, stride, act, x.c, out_f32,
-                          None if out_f32 else tuning.lookup(k, stride, x.c, cout, ho, wo))
+                          None if out_f32 else tuning.lookup(k, stride, x.c, cout, ho, wo), residual_scale)
         if out2 is not None:
             assert out is not None and residual is None and not out_f32
             assert (out.h, out.w, out2.h, out2.w) == (ho, wo, ho, wo) and out.c + out2.c == cout and out.c % 8 == 0

@@ -20,7 +20,7 @@ EXPORTS = [
     "yamd_last_error", "yamd_version", "yamd_conv_desc_init", "yamd_conv_desc_tune", "yamd_conv_pack_weights", "yamd_conv2d_bias_act", "yamd_conv2d_bias_act_split",
     "yamd_focus_pack", "yamd_nchw_to_nhwc16", "yamd_upsample2x", "yamd_maxpool2", "yamd_maxpool5_cascade", "yamd_maxpool3_cascade",
     "yamd_copy_channels", "yamd_depth_to_space2", "yamd_decode_ltrb_points",
-    "yamd_decode_anchor", "yamd_decode_dfl", "yamd_nms_workspace_bytes", "yamd_nms_batched", "yamd_compact_rows", "yamd_letterbox_workspace_bytes", "yamd_letterbox_u8", "yamd_detect_match", "yamd_stem_packed_elems", "yamd_stem_pack_weights", "yamd_stem_conv",
+    "yamd_decode_anchor", "yamd_decode_dfl", "yamd_decode_dfl_unit_conf", "yamd_nms_workspace_bytes", "yamd_nms_batched", "yamd_compact_rows", "yamd_letterbox_workspace_bytes", "yamd_letterbox_u8", "yamd_detect_match", "yamd_stem_packed_elems", "yamd_stem_pack_weights", "yamd_stem_conv",
 ]
 
 
@@ -28,7 +28,7 @@ class ConvDesc(ctypes.Structure):
     """Mirror of ``yamd_conv_desc``."""
     _fields_ = [("ksize", c_int32), ("stride", c_int32), ("cin", c_int32), ("cout", c_int32), ("act", c_int32),
                 ("out_f32", c_int32), ("nrep", c_int32), ("ck", c_int32), ("mrep", c_int32), ("cout_pad", c_int32),
-                ("packed_w_elems", c_int64), ("nwaves", c_int32), ("reserved", c_int32)]
+                ("packed_w_elems", c_int64), ("nwaves", c_int32), ("residual_scale", ctypes.c_float)]
 
 
 class YamdError(RuntimeError):
@@ -68,6 +68,7 @@ def _load() -> ctypes.CDLL:
                                        c_float, c_int, c_int, c_void_p, c_longlong, c_longlong, c_void_p]
     lib.yamd_decode_dfl.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p, c_void_p]
+    lib.yamd_decode_dfl_unit_conf.argtypes = lib.yamd_decode_dfl.argtypes
     lib.yamd_decode_ltrb_points.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                             c_void_p, c_void_p]
     lib.yamd_detect_match.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_float, c_float,

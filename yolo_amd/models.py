@@ -43,6 +43,14 @@ def registry() -> Dict[str, Dict[str, Any]]:
         "v6": dict(cls=YoloV6, param=lambda: _param.Yolo6Param(m_type="s"),
                    init=dict(scale={".rbr_dense.bn.weight": 0.55, ".rbr_1x1.bn.weight": 0.55,
                                     ".rbr_identity.weight": 0.55, "reg_predict_list": 0.3})),
+        # m/l: BottleRep pairs with a learned shortcut weight; alpha away from 1 so that the scaling is exercised and the
+        # residual stacks keep their range; DFL logits with a std near 2 give varied box sizes
+        "v6m": dict(cls=YoloV6, param=lambda: _param.Yolo6Param(m_type="m"),
+                    init=dict(scale={".rbr_dense.bn.weight": 0.55, ".rbr_1x1.bn.weight": 0.55,
+                                     ".rbr_identity.weight": 0.55, "reg_predict_list": 2.0, ".alpha": 0.6,
+                                     ".cv3.block.bn.weight": 0.5})),
+        "v6l": dict(cls=YoloV6, param=lambda: _param.Yolo6Param(m_type="l"),
+                    init=dict(scale={"reg_predict_list": 2.0, ".alpha": 0.6, ".cv3.block.bn.weight": 0.5})),
         "v6pose": dict(cls=YoloV6Pose, param=lambda: _param.Yolo6PoseParam(m_type="s"),
                        init=dict(scale={".rbr_dense.bn.weight": 0.55, ".rbr_1x1.bn.weight": 0.55,
                                         ".rbr_identity.weight": 0.55, "reg_predict_list": 0.3,
@@ -144,7 +152,7 @@ def from_state_dict(sd, img_size: int, output_size: int = 0, point_num: int = 0)
             p, cls = with_classes(_param.Yolo7Param(m_type=t), oc - 5), YoloV7
     elif any(k.startswith("yolo_body.back_bone_network.stem.") for k in keys):
         k = "yolo_body.head.stems.0.block.conv.weight"
-        t = width_type(sd[k].shape[0], {"n": 32, "s": 64})
+        t = width_type(sd[k].shape[0], {"n": 32, "s": 64, "m": 96, "l": 128})
         from .yolov6_face import YoloV6
         pk = "yolo_body.head.reg_point_predict_list.0.weight"
         from .yolov6_face import YoloV6Pose

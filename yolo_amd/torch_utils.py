@@ -133,8 +133,10 @@ def decode_anchor_head(raw: torch.Tensor, anchors, stride: int, kind: int, point
     return out
 
 
-def decode_dfl(raws: List[torch.Tensor], strides, reg_max: int, nc: int, out_fmt: str) -> torch.Tensor:
-    """raws[i]: (B,h,w,4*reg_max+nc) float32 NHWC.  Returns (B, A, 5+nc): [box, max score, scores]."""
+def decode_dfl(raws: List[torch.Tensor], strides, reg_max: int, nc: int, out_fmt: str, unit_conf: bool = False
+               ) -> torch.Tensor:
+    """raws[i]: (B,h,w,4*reg_max+nc) float32 NHWC.  Returns (B, A, 5+nc): [box, max score, scores]; with
+    ``unit_conf`` (YOLOv6 m/l, reg_max = 17 bins) column 4 is the constant 1.0."""
     B = raws[0].shape[0]
     n = len(raws)
     for r in raws:
@@ -145,8 +147,9 @@ def decode_dfl(raws: List[torch.Tensor], strides, reg_max: int, nc: int, out_fmt
     hs = (ctypes.c_int * n)(*[r.shape[1] for r in raws])
     ws = (ctypes.c_int * n)(*[r.shape[2] for r in raws])
     ss = (ctypes.c_int * n)(*[int(s) for s in strides])
-    _lib.check(LIB.yamd_decode_dfl(ptrs, hs, ws, ss, n, B, reg_max, nc, 1 if out_fmt == "cxcywh" else 0,
-                                   out.data_ptr(), _lib.current_stream()), "decode_dfl")
+    fn = LIB.yamd_decode_dfl_unit_conf if unit_conf else LIB.yamd_decode_dfl
+    _lib.check(fn(ptrs, hs, ws, ss, n, B, reg_max, nc, 1 if out_fmt == "cxcywh" else 0, out.data_ptr(),
+                  _lib.current_stream()), "decode_dfl")
     return out
 
 

@@ -7,7 +7,10 @@ and the module tree of luoyang/yolov6_face/YoloV6FaceBody.py (ConvModule :98-134
 create_head :1070-1182, YoloV6FaceHead :1230-1455), so ``state_dict`` keys are identical before and after ``fuse()``.
 Every BatchNorm runs with eps 1e-3 (YoloV6FaceBody.py:1479-1486).  RepVGG blocks are re-parameterised to a single
 3x3 conv + ReLU when the plan is compiled; ConvTranspose2d(2,2) runs as a 1x1 conv + depth-to-space.
-The m/l variants (CSPBep backbone, DFL-17 head) are not built.
+The detect model also comes as m/l (``YoloV6`` only): CSPBepBackboneP6 / CSPRepBiFPANNeckP6 of luoyang/yolov6/YoloV6Body.py
+(:811-906, :909-1022) made of BepC3 (:719-739) over BottleRep pairs with a learned shortcut weight (:427-472), SimSPPF /
+SPPF (:321-369) and a 17-bin DFL box head (:1322-1343); m uses RepVGG blocks + ReLU, l uses conv + SiLU (:1185-1188).
+The face and pose m/l variants are not built.
 """
 import math
 from typing import Any, Dict, List
@@ -19,10 +22,12 @@ import torch.nn.functional as F
 from . import lib as _lib
 from . import torch_utils
 from .engine import Program, View
-from .graph import Recorder, TaskModel, conv_bn
+from .graph import Recorder, TaskModel, conv_bn, folded
 from .param import Yolo6FaceParam
 
-_CFG = {"s": (0.33, 0.50), "n": (0.33, 0.25)}
+_CFG = {"s": (0.33, 0.50), "n": (0.33, 0.25), "m": (0.60, 0.75), "l": (1.0, 1.0)}
+_CSP_E = {"m": 2.0 / 3, "l": 0.5}            # create_body / create_neck, YoloV6Body.py:1042, :1063
+DFL_BINS = 17                                 # reg_max 16 -> 17 logits per box side
 _BACKBONE = ([1, 6, 12, 18, 6, 6], [64, 128, 256, 512, 768, 1024])
 _NECK = ([12] * 6, [512, 256, 128, 256, 512, 1024])
 
@@ -98,37 +103,82 @@ def _bifusion(cins, cout) -> nn.Module:
     return m
 
 
+def _bottle_rep(c: int, basic) -> nn.Module:
+    """BottleRep(c, c, weight=True) (YoloV6Body.py:451-472): two basic blocks and x * alpha added to their output."""
+    m = nn.Module()
+    m.conv1, m.conv2 = basic(c, c), basic(c, c)
+    m.alpha = nn.Parameter(torch.ones(1))
+    return m
+
+
+def _bep_c3(cin: int, cout: int, n: int, e: float, basic) -> nn.Module:
+    """BepC3 (YoloV6Body.py:719-739) with its RepBlock of n // 2 BottleReps (:427-449)."""
+    m = nn.Module()
+    c_ = int(cout * e)
+    m.cv1, m.cv2, m.cv3 = _wrapped(cin, c_, 1), _wrapped(cin, c_, 1), _wrapped(2 * c_, cout, 1)
+    rb = nn.Module()
+    rb.conv1 = _bottle_rep(c_, basic)
+    n = n // 2
+    rb.block = nn.Sequential(*(_bottle_rep(c_, basic) for _ in range(n - 1))) if n > 1 else None
+    m.m = rb
+    return m
+
+
+def _sppf(cin: int, cout: int, attr: str) -> nn.Module:
+    """SimSPPF (``spp_f``) / SPPF (``sppf``) around SPPFModule (YoloV6Body.py:321-369)."""
+    m, inner = nn.Module(), nn.Module()
+    c_ = cin // 2
+    inner.cv1, inner.cv2 = _wrapped(cin, c_, 1), _wrapped(4 * c_, cout, 1)
+    setattr(m, attr, inner)
+    return m
+
+
 def _tree(param) -> nn.Module:
     if param.m_type not in _CFG:
-        raise NotImplementedError(f"YoloV6Face m_type={param.m_type!r}: only the n/s variants are built on the HIP path")
+        raise NotImplementedError(f"YoloV6 m_type={param.m_type!r} is not built on the HIP path")
+    csp = param.m_type in _CSP_E
+    if csp and getattr(param, "point_num", 0):
+        raise NotImplementedError(f"m_type={param.m_type!r}: only the detect model is built as m/l; face and pose are n/s")
     dm, wm = _CFG[param.m_type]
     rep = [(max(round(i * dm), 1) if i > 1 else i) for i in (_BACKBONE[0] + _NECK[0])]
     ch = [math.ceil(i * wm / 8) * 8 for i in (_BACKBONE[1] + _NECK[1])]
+    if csp:
+        e = _CSP_E[param.m_type]
+        basic = (lambda a, b, s=1: rep_vgg(a, b, s)) if param.m_type == "m" else (lambda a, b, s=1: _wrapped(a, b, 3, s))
+
+        def stage(cin, cout, n):
+            return _bep_c3(cin, cout, n, e, basic)
+    else:
+        basic, stage = rep_vgg, _rep_block
+    fusion = "bi_fusion" if csp else "Bi_fusion"          # attribute names of the two neck classes (:929 vs :624)
     body = nn.Module()
     bb = nn.Module()
-    bb.stem = rep_vgg(3, ch[0], 2)
+    bb.stem = basic(3, ch[0], 2)
     for i in range(1, 6):
-        mods = [rep_vgg(ch[i - 1], ch[i], 2), _rep_block(ch[i], ch[i], rep[i])]
+        mods = [basic(ch[i - 1], ch[i], 2), stage(ch[i], ch[i], rep[i])]
         if i == 5:
-            mods.append(_csp_sppf(ch[5], ch[5]))
+            if csp:
+                mods.append(_sppf(ch[5], ch[5], "spp_f" if param.m_type == "m" else "sppf"))
+            else:
+                mods.append(_csp_sppf(ch[5], ch[5]))
         bb.add_module(f"ERBlock_{i + 1}", nn.Sequential(*mods))
     body.back_bone_network = bb
     nk = nn.Module()
     nk.reduce_layer0 = _wrapped(ch[5], ch[6], 1)
-    nk.Bi_fusion_0 = _bifusion([ch[4], ch[6]], ch[6])
-    nk.Rep_p5 = _rep_block(ch[6], ch[6], rep[6])
+    setattr(nk, f"{fusion}_0", _bifusion([ch[4], ch[6]], ch[6]))
+    nk.Rep_p5 = stage(ch[6], ch[6], rep[6])
     nk.reduce_layer1 = _wrapped(ch[6], ch[7], 1)
-    nk.Bi_fusion_1 = _bifusion([ch[3], ch[7]], ch[7])
-    nk.Rep_p4 = _rep_block(ch[7], ch[7], rep[7])
+    setattr(nk, f"{fusion}_1", _bifusion([ch[3], ch[7]], ch[7]))
+    nk.Rep_p4 = stage(ch[7], ch[7], rep[7])
     nk.reduce_layer2 = _wrapped(ch[7], ch[8], 1)
-    nk.Bi_fusion_2 = _bifusion([ch[2], ch[8]], ch[8])
-    nk.Rep_p3 = _rep_block(ch[8], ch[8], rep[8])
+    setattr(nk, f"{fusion}_2", _bifusion([ch[2], ch[8]], ch[8]))
+    nk.Rep_p3 = stage(ch[8], ch[8], rep[8])
     nk.down_sample_2 = _wrapped(ch[8], ch[8], 3, 2)
-    nk.Rep_n4 = _rep_block(ch[8] + ch[8], ch[9], rep[9])
+    nk.Rep_n4 = stage(ch[8] + ch[8], ch[9], rep[9])
     nk.down_sample_1 = _wrapped(ch[9], ch[9], 3, 2)
-    nk.Rep_n5 = _rep_block(ch[7] + ch[9], ch[10], rep[10])
+    nk.Rep_n5 = stage(ch[7] + ch[9], ch[10], rep[10])
     nk.down_sample_0 = _wrapped(ch[10], ch[10], 3, 2)
-    nk.Rep_n6 = _rep_block(ch[6] + ch[10], ch[11], rep[11])
+    nk.Rep_n6 = stage(ch[6] + ch[10], ch[11], rep[11])
     body.neck_network = nk
     hd = nn.Module()
     hc = [ch[8], ch[9], ch[10], ch[11]][:param.num_layers] if param.num_layers == 4 else [ch[6], ch[8], ch[10]]
@@ -140,7 +190,7 @@ def _tree(param) -> nn.Module:
         hd.reg_point_conv_list = nn.ModuleList(_wrapped(c, c, 3) for c in hc)
     ncp = nc + (P if getattr(param, "point_conf", False) else 0)     # pose: one confidence logit per keypoint after the classes
     hd.cls_predict_list = nn.ModuleList(nn.Conv2d(c, ncp, 1) for c in hc)
-    hd.reg_predict_list = nn.ModuleList(nn.Conv2d(c, 4, 1) for c in hc)
+    hd.reg_predict_list = nn.ModuleList(nn.Conv2d(c, 4 * DFL_BINS if csp else 4, 1) for c in hc)
     if P:
         hd.reg_point_predict_list = nn.ModuleList(nn.Conv2d(c, 2 * P, 1) for c in hc)
     hd.proj = nn.Parameter(torch.linspace(0, 16, 17), requires_grad=False)
@@ -164,20 +214,45 @@ class YoloV6Face(TaskModel):
         self.point_num = getattr(param, "point_num", 0)
         self.point_conf = bool(getattr(param, "point_conf", False)) and self.point_num > 0
         self.yolo_body = _tree(param)
+        self.box_channels = 4 * DFL_BINS if param.m_type in _CSP_E else 4        # raw box logits per cell
         self.eval()
 
     # ---- graph -----------------------------------------------------------------------------------
     @staticmethod
-    def _rv(R: Recorder, name: str, m: nn.Module, x: View) -> View:
-        w, b = rep_vgg_equivalent(m)
-        return R.p.conv(name, x, w, b, m.stride, _lib.ACT_RELU)
+    def _rv(R: Recorder, name: str, m: nn.Module, x: View, **kw) -> View:
+        """A basic block: RepVGG (one 3x3 conv + ReLU once re-parameterised) or, in the l model, ConvBNSiLU."""
+        if getattr(m, "is_rep_vgg", False):
+            w, b = rep_vgg_equivalent(m)
+            return R.p.conv(name, x, w, b, m.stride, _lib.ACT_RELU, **kw)
+        w, b, s = folded(m.block)
+        return R.p.conv(name, x, w, b, s, _lib.ACT_SILU, **kw)
 
     def _rb(self, R: Recorder, name: str, m: nn.Module, x: View) -> View:
+        if hasattr(m, "cv3"):
+            return self._bep_c3(R, name, m, x)
         x = self._rv(R, f"{name}.conv1", m.conv1, x)
         if m.block is not None:
             for i, b in enumerate(m.block):
                 x = self._rv(R, f"{name}.block.{i}", b, x)
         return x
+
+    def _bep_c3(self, R: Recorder, name: str, m: nn.Module, x: View) -> View:
+        """cv3(cat(m(cv1(x)), cv2(x))).  cv1 and cv2 read the same input and run as one conv writing side by side into
+        [m out | cv2 out | cv1 out]; the last BottleRep writes the first slice and cv3 reads the first two."""
+        act = _lib.ACT_SILU if self.param.m_type == "l" else _lib.ACT_RELU
+        c_ = m.cv1.block.conv.out_channels
+        (w1, b1, _), (w2, b2, _) = folded(m.cv1.block), folded(m.cv2.block)
+        buf = R.p.buffer(x.h, x.w, 3 * c_)
+        R.p.conv(f"{name}.cv2+cv1", x, torch.cat((w2, w1), 0), torch.cat((b2, b1), 0), 1, act, out=buf.slice(c_, 2 * c_))
+        a = buf.slice(2 * c_, c_)
+        bots = [(f"{name}.m.conv1", m.m.conv1)]
+        if m.m.block is not None:
+            bots += [(f"{name}.m.block.{i}", b) for i, b in enumerate(m.m.block)]
+        for i, (bn, bot) in enumerate(bots):
+            t = self._rv(R, f"{bn}.conv1", bot.conv1, a)
+            a = self._rv(R, f"{bn}.conv2", bot.conv2, t, out=buf.slice(0, c_) if i == len(bots) - 1 else None,
+                         residual=a, residual_scale=float(bot.alpha.detach()))
+        return self._w(R, f"{name}.cv3", m.cv3, buf.slice(0, 2 * c_), act)
 
     @staticmethod
     def _w(R: Recorder, name: str, m: nn.Module, x: View, act: int, out=None) -> View:
@@ -194,6 +269,8 @@ class YoloV6Face(TaskModel):
     def _compile(self, S: int) -> Program:
         bb, nk, hd = self.yolo_body.back_bone_network, self.yolo_body.neck_network, self.yolo_body.head
         relu, silu = _lib.ACT_RELU, _lib.ACT_SILU
+        csp = self.param.m_type in _CSP_E
+        fusion = [getattr(nk, f"{'bi_fusion' if csp else 'Bi_fusion'}_{i}") for i in range(3)]
         P = Program(S, S)
         R = Recorder(P, relu)
         x = self._rv(R, "stem", bb.stem, P.image16(3))
@@ -201,7 +278,14 @@ class YoloV6Face(TaskModel):
         for i in range(2, 7):
             blk = getattr(bb, f"ERBlock_{i}")
             x = self._rb(R, f"ERBlock_{i}.1", blk[1], self._rv(R, f"ERBlock_{i}.0", blk[0], x))
-            if i == 6:
+            if i == 6 and csp:
+                sp, a = (blk[2].spp_f, relu) if hasattr(blk[2], "spp_f") else (blk[2].sppf, silu)
+                c_ = sp.cv1.block.conv.out_channels
+                cat = P.buffer(x.h, x.w, 4 * c_, name="cat_sppf")
+                self._w(R, "sppf.cv1", sp.cv1, x, a, out=cat.slice(0, c_))
+                P.maxpool5_cascade(cat.slice(0, c_), cat.slice(c_, c_), cat.slice(2 * c_, c_), cat.slice(3 * c_, c_))
+                x = self._w(R, "sppf.cv2", sp.cv2, cat, a)
+            elif i == 6:
                 sp = blk[2].cspsppf
                 c_ = sp.cv4.block.conv.out_channels
                 cat = P.buffer(x.h, x.w, 4 * c_, name="cat_sppf")
@@ -215,25 +299,27 @@ class YoloV6Face(TaskModel):
         x4, x3, x2, x1, x0 = feats
 
         fpn0 = self._w(R, "reduce_layer0", nk.reduce_layer0, x0, relu)
-        f0 = self._rb(R, "Rep_p5", nk.Rep_p5, self._bifusion(R, "Bi_fusion_0", nk.Bi_fusion_0, [fpn0, x1, x2]))
+        f0 = self._rb(R, "Rep_p5", nk.Rep_p5, self._bifusion(R, "bi_fusion_0", fusion[0], [fpn0, x1, x2]))
         fpn1 = self._w(R, "reduce_layer1", nk.reduce_layer1, f0, relu)
-        f1 = self._rb(R, "Rep_p4", nk.Rep_p4, self._bifusion(R, "Bi_fusion_1", nk.Bi_fusion_1, [fpn1, x2, x3]))
+        f1 = self._rb(R, "Rep_p4", nk.Rep_p4, self._bifusion(R, "bi_fusion_1", fusion[1], [fpn1, x2, x3]))
         fpn2 = self._w(R, "reduce_layer2", nk.reduce_layer2, f1, relu)
-        pan3 = self._rb(R, "Rep_p3", nk.Rep_p3, self._bifusion(R, "Bi_fusion_2", nk.Bi_fusion_2, [fpn2, x3, x4]))
+        pan3 = self._rb(R, "Rep_p3", nk.Rep_p3, self._bifusion(R, "bi_fusion_2", fusion[2], [fpn2, x3, x4]))
         pan2 = self._rb(R, "Rep_n4", nk.Rep_n4, P.cat([self._w(R, "down_sample_2", nk.down_sample_2, pan3, relu), fpn2]))
         pan1 = self._rb(R, "Rep_n5", nk.Rep_n5, P.cat([self._w(R, "down_sample_1", nk.down_sample_1, pan2, relu), fpn1]))
         pan0 = self._rb(R, "Rep_n6", nk.Rep_n6, P.cat([self._w(R, "down_sample_0", nk.down_sample_0, pan1, relu), fpn0]))
 
         nc, K = self.param.class_num, 2 * self.point_num
         ncp = nc + (self.point_num if self.point_conf else 0)
+        nb = self.box_channels
         for i, t in enumerate((pan3, pan2, pan1, pan0)[:self.param.num_layers]):
-            raw = P.buffer(t.h, t.w, 4 + K + ncp, torch.float32, name=f"raw{i}")      # [ltrb | landmarks | (kpt conf) | cls]
+            # [ltrb (or 4 x 17 DFL logits) | landmarks | (kpt conf) | cls]
+            raw = P.buffer(t.h, t.w, nb + K + ncp, torch.float32, name=f"raw{i}")
             s = self._w(R, f"head.stems.{i}", hd.stems[i], t, silu)
             R.head(f"head.reg_pred.{i}", hd.reg_predict_list[i],
-                   self._w(R, f"head.reg_conv.{i}", hd.reg_conv_list[i], s, silu), out=raw.slice(0, 4))
+                   self._w(R, f"head.reg_conv.{i}", hd.reg_conv_list[i], s, silu), out=raw.slice(0, nb))
             if K:
                 R.head(f"head.point_pred.{i}", hd.reg_point_predict_list[i],
-                       self._w(R, f"head.point_conv.{i}", hd.reg_point_conv_list[i], s, silu), out=raw.slice(4, K))
+                       self._w(R, f"head.point_conv.{i}", hd.reg_point_conv_list[i], s, silu), out=raw.slice(nb, K))
             cp = hd.cls_predict_list[i]
             cw, cb = cp.weight.detach(), cp.bias.detach()
             if self.point_conf:
@@ -241,18 +327,20 @@ class YoloV6Face(TaskModel):
                 # the order of its output columns, confidences first, so the kernel can treat both as "scores"
                 cw, cb = torch.cat((cw[nc:], cw[:nc]), 0), torch.cat((cb[nc:], cb[:nc]), 0)
             P.conv(f"head.cls_pred.{i}", self._w(R, f"head.cls_conv.{i}", hd.cls_conv_list[i], s, silu), cw, cb, 1,
-                   _lib.ACT_NONE, out=raw.slice(4 + K, ncp), out_f32=True)
+                   _lib.ACT_NONE, out=raw.slice(nb + K, ncp), out_f32=True)
             P.outputs[f"L{i}"] = raw
         return P
 
     # ---- reference interface -------------------------------------------------------------------
     def raw_heads(self, images: torch.Tensor) -> List[torch.Tensor]:
         """Raw head tensors per level, float32 NHWC (B,h,w,4+2P+nc), channel order [ltrb | landmarks | cls]
-        (pose: [ltrb | keypoints | keypoint confidences | cls])."""
+        (pose: [ltrb | keypoints | keypoint confidences | cls]; detect m/l: [4 x 17 DFL logits | cls])."""
         out = self.program().run(images)
         return [out[f"L{i}"] for i in range(self.param.num_layers)]
 
     def _decode(self, raws, fmt: str) -> torch.Tensor:
+        if self.box_channels != 4:
+            return torch_utils.decode_dfl(raws, self.param.strides, DFL_BINS, self.param.class_num, fmt, unit_conf=True)
         ncp = self.param.class_num + (self.point_num if self.point_conf else 0)
         return torch_utils.decode_ltrb_points(raws, self.param.strides, self.point_num, ncp, fmt)
 
@@ -275,7 +363,8 @@ class YoloV6Face(TaskModel):
         tensor_dict["predict_xy_xy"] = pred[..., :4]
         if K:
             tensor_dict["point_predict_xy"] = pred[..., 5:5 + K]
-        tensor_dict["reg_distribute_tensor"] = torch.cat([r[..., :4].reshape(B, -1, 4) for r in raws], 1)
+        nb = self.box_channels
+        tensor_dict["reg_distribute_tensor"] = torch.cat([r[..., :nb].reshape(B, -1, nb) for r in raws], 1)
         tensor_dict["num_anchors_list"] = [r.shape[1] * r.shape[2] for r in raws]
         tensor_dict["stride_tensor"] = torch.cat([torch.full((r.shape[1] * r.shape[2], 1), float(s), device=pred.device)
                                                   for r, s in zip(raws, self.param.strides)])
@@ -315,7 +404,7 @@ class YoloV6Face(TaskModel):
 
 
 class YoloV6(YoloV6Face):
-    """``YoloV6(param)`` (detect, n/s): the graph of luoyang/yolov6/YoloV6Body.py is the face graph without the landmark
+    """``YoloV6(param)`` (detect, n/s/m/l): for n/s the graph of luoyang/yolov6/YoloV6Body.py is the face graph without the landmark
     branch of the head (five modules per level instead of seven, :1071-1165, :1245-1252); ``_forward`` /
     ``predict`` as luoyang/yolov6/YoloV6.py:41-83.  ``predicts`` rows: [x1,y1,x2,y2, 1.0, cls_conf, cls_id]."""
 
