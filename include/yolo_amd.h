@@ -171,6 +171,13 @@ int yamd_decode_dfl_unit_conf(const float *const *raw_host_ptrs, const int *hs_h
 int yamd_decode_ltrb_points(const float *const *raw_host_ptrs, const int *hs_host, const int *ws_host,
                             const int *strides_host, int n_levels, int batch, int point_num, int nc, int out_cxcywh,
                             float *out, void *stream);
+/* The same rows for the m/l widths of the YOLOv6 face and pose heads, whose box branch is a DFL distribution
+ * (yolov6_face/YoloV6FaceBody.py:1354-1376 bbox_decode with use_dfl, :1426-1429): raw[i] is
+ * (batch,h_i,w_i,4*bins+2*point_num+nc), channel order [4 x bins box logits | landmarks | cls]; each box distance is the
+ * expectation of softmax(bins logits) over 0..bins-1 (bins = reg_max + 1 = 17). */
+int yamd_decode_dfl_points(const float *const *raw_host_ptrs, const int *hs_host, const int *ws_host,
+                           const int *strides_host, int n_levels, int batch, int bins, int point_num, int nc,
+                           int out_cxcywh, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Confidence filter + per-class greedy NMS for a whole batch; replaces the Python per-image loop

@@ -146,8 +146,16 @@ def decode_dfl(raws: List[np.ndarray], strides: Sequence[int], reg_max: int, num
     return np.concatenate((box, conf, sc), -1).astype(F32)
 
 
+def _dfl_expectation(d: np.ndarray) -> np.ndarray:
+    """softmax over the last axis projected on 0..bins-1 (F.softmax(..).matmul(proj), YoloV6FaceBody.py:1363-1372)."""
+    d = d - d.max(axis=-1, keepdims=True)
+    e = np.exp(d, dtype=F32)
+    sm = e / e.sum(axis=-1, keepdims=True, dtype=F32)
+    return (sm * np.arange(d.shape[-1], dtype=F32)).sum(axis=-1, dtype=F32)
+
+
 def decode_ltrb_points(raws: List[np.ndarray], strides: Sequence[int], point_num: int, num_classes: int,
-                       out_fmt: str) -> np.ndarray:
+                       out_fmt: str, bins: int = 1) -> np.ndarray:
     """v6 face without DFL (luoyang/yolov6_face/YoloV6FaceBody.py:1354-1397, :1439-1455; assembled by
     luoyang/yolov6_face/YoloV6Face.py:42-58 / :66-74): raws[i] (B, 4+2P+nc, H, W) in the order [ltrb | landmarks | cls]
     -> (B, A, 5+2P+nc) = [box, 1.0, landmarks, sigmoid(cls)]; box xyxy (predict) or cxcywh (_forward), pixels."""
@@ -155,6 +163,8 @@ def decode_ltrb_points(raws: List[np.ndarray], strides: Sequence[int], point_num
     for raw, s in zip(raws, strides):
         B, ch, H, W = raw.shape
         t = raw.astype(F32).reshape(B, ch, H * W).transpose(0, 2, 1)
+        if bins > 1:         # m/l: the four distances are DFL expectations of 4 x bins logits
+            t = np.concatenate((_dfl_expectation(t[..., :4 * bins].reshape(B, H * W, 4, bins)), t[..., 4 * bins:]), -1)
         fs = F32(s)
         ys, xs = np.meshgrid(np.arange(H, dtype=F32), np.arange(W, dtype=F32), indexing="ij")
         ax = (((xs.reshape(-1) + F32(0.5)) * fs) / fs).astype(F32)

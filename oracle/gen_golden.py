@@ -281,6 +281,9 @@ def _ref_models():
         "v6": (_lazy("luoyang.yolov6.YoloV6", "YoloV6"), lambda: _lazy("luoyang.param.Param", "Yolo6Param")(m_type="s"), "v6", 7, 128),
         "v6m": (_lazy("luoyang.yolov6.YoloV6", "YoloV6"), lambda: _lazy("luoyang.param.Param", "Yolo6Param")(m_type="m"), "v6", 7, 128),
         "v6l": (_lazy("luoyang.yolov6.YoloV6", "YoloV6"), lambda: _lazy("luoyang.param.Param", "Yolo6Param")(m_type="l"), "v6", 7, 128),
+        "v6facem": (YoloV6Face, lambda: Yolo6FaceParam(m_type="m"), "v6", 6 + 2 * 5 + 1, 128),
+        "v6posel": (_lazy("luoyang.yolov6_pose.YoloV6Pose", "YoloV6Pose"), lambda: _lazy("luoyang.param.Param", "Yolo6PoseParam")(m_type="l"),
+                    "v6", 6 + 3 * 17 + 1, 128),
         "v6pose": (_lazy("luoyang.yolov6_pose.YoloV6Pose", "YoloV6Pose"), lambda: _lazy("luoyang.param.Param", "Yolo6PoseParam")(m_type="s"),
                    "v6", 6 + 3 * 17 + 1, 128),
         "v7": (_lazy("luoyang.yolov7.YoloV7", "YoloV7"), lambda: _lazy("luoyang.param.Param", "Yolo7Param")(m_type="l"), "desc", 7, 64),

@@ -389,7 +389,7 @@ def v6pose_body(sd: SD, images: torch.Tensor) -> List[torch.Tensor]:
     outs = []
     for i, r in enumerate(v6face_body(sd, images)):
         P = sd[f"yolo_body.head.reg_point_predict_list.{i}.weight"].shape[0] // 2
-        k = 4 + 2 * P
+        k = sd[f"yolo_body.head.reg_predict_list.{i}.weight"].shape[0] + 2 * P
         nc = r.shape[1] - k - P
         outs.append(torch.cat((r[:, :k], r[:, k + nc:], r[:, k:k + nc]), 1))
     return outs
@@ -446,15 +446,17 @@ def model_ref(name: str):
                     decode=lambda raws, p, predict: decode_ref.decode_ltrb_points(raws, p.strides, 0, p.class_num,
                                                                                   "xyxy" if predict else "cxcywh"),
                     nms=dict(in_fmt="xyxy"))
-    if name == "v6pose":
+    if name in ("v6pose", "v6posel"):
+        bins = 17 if name == "v6posel" else 1
         return dict(body=v6pose_body,
                     decode=lambda raws, p, predict: decode_ref.decode_ltrb_points(raws, p.strides, p.point_num,
                                                                                   p.class_num + p.point_num,
-                                                                                  "xyxy" if predict else "cxcywh"),
+                                                                                  "xyxy" if predict else "cxcywh", bins),
                     nms=dict(in_fmt="xyxy", point_num=17, point_conf=True))
-    if name in ("v6face", "v6facen"):
+    if name in ("v6face", "v6facen", "v6facem"):
+        bins = 17 if name == "v6facem" else 1
         return dict(body=v6face_body,
                     decode=lambda raws, p, predict: decode_ref.decode_ltrb_points(raws, p.strides, p.point_num, p.class_num,
-                                                                                  "xyxy" if predict else "cxcywh"),
+                                                                                  "xyxy" if predict else "cxcywh", bins),
                     nms=dict(in_fmt="xyxy", point_num=5, point_conf=False))
     raise KeyError(name)

@@ -55,6 +55,22 @@ def test_decode_dfl_17_bins_unit_conf(gpu_device):
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("P,nc", [(5, 1), (17, 18)])
+def test_decode_dfl_points_vs_oracle(gpu_device, P, nc):
+    """m/l face / pose heads: 17-bin DFL box sides next to the landmark columns; bins = 1 stays the plain ltrb decode."""
+    from oracle import decode_ref as D
+    from yolo_amd import torch_utils as tu
+    rng = np.random.RandomState(9 + P)
+    strides, sizes = [8, 16, 32, 64], [(16, 24), (8, 12), (4, 6), (2, 3)]
+    for bins in (17, 1):
+        raws = [(rng.standard_normal((3, 4 * bins + 2 * P + nc, h, w)) * 2.0).astype(np.float32) for h, w in sizes]
+        dev = [_nhwc(r, gpu_device) for r in raws]
+        for fmt in ("cxcywh", "xyxy"):
+            want = D.decode_ltrb_points(raws, strides, P, nc, fmt, bins)
+            got = tu.decode_ltrb_points(dev, strides, P, nc, fmt, bins=bins).cpu().numpy()
+            np.testing.assert_allclose(got, want, rtol=1e-5, atol=2e-4)
+
+
 def test_decode_dfl_vs_golden(gpu_device):
     from yolo_amd import torch_utils as tu
     G = load_golden("decode.npz")

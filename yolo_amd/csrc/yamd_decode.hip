@@ -177,11 +177,12 @@ __global__ __launch_bounds__(256) void decode_dfl_kernel(DflParams p)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Anchor-free ltrb + landmark decode (no DFL): one workgroup per DPIX pixels of one level.
+// Anchor-free ltrb + landmark decode: one workgroup per DPIX pixels of one level.  bins == 1: the four box distances
+// are the raw values; bins > 1: each is the expectation of softmax(bins logits) over 0..bins-1 (DFL).
 struct LtrbParams {
     const float *raw;
     float *out;
-    int H, W, P, nc, stride, out_cxcywh;
+    int H, W, P, nc, stride, out_cxcywh, bins;
     long long rows_per_image, row_offset;
 };
 
@@ -189,25 +190,45 @@ __global__ __launch_bounds__(256) void decode_ltrb_kernel(LtrbParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int HW = p.H * p.W;
-    const int CI = 4 + 2 * p.P + p.nc;     // input channels per pixel
+    const int NB = 4 * p.bins;             // box channels per pixel
+    const int CI = NB + 2 * p.P + p.nc;    // input channels per pixel
     const int CO = 5 + 2 * p.P + p.nc;     // output columns
     float *sraw = sm;                      // DPIX * CI
     float *sout = sm + DPIX * CI;          // DPIX * CO
+    float *sd = sout + DPIX * CO;          // DPIX * 4 box distances in grid units
     const int p0 = blockIdx.x * DPIX;
     const int np = min(DPIX, HW - p0);
     const long long b = blockIdx.y;
     const float *src = p.raw + (b * HW + p0) * (long long)CI;
     for (int i = threadIdx.x; i < np * CI; i += 256) sraw[i] = src[i];
     __syncthreads();
+    if (threadIdx.x < 4 * DPIX) {
+        const int pix = threadIdx.x >> 2, side = threadIdx.x & 3;
+        if (pix < np) {
+            const float *d = sraw + pix * CI + side * p.bins;
+            float e = d[0];
+            if (p.bins > 1) {
+                float mx = d[0];
+                for (int i = 1; i < p.bins; ++i) mx = fmaxf(mx, d[i]);
+                float sum = 0.0f;
+                for (int i = 0; i < p.bins; ++i) sum += expf(d[i] - mx);
+                e = 0.0f;
+                for (int i = 0; i < p.bins; ++i) e += (expf(d[i] - mx) / sum) * (float)i;
+            }
+            sd[pix * 4 + side] = e;
+        }
+    }
+    __syncthreads();
     const float fs = (float)p.stride;
     for (int i = threadIdx.x; i < np * CO; i += 256) {
         const int pix = i / CO, c = i % CO, gp = p0 + pix;
         // cell centre in grid units, computed like the reference: ((index + 0.5) * stride) / stride
         const float ax = (((float)(gp % p.W) + 0.5f) * fs) / fs, ay = (((float)(gp / p.W) + 0.5f) * fs) / fs;
-        const float *r = sraw + pix * CI;
+        const float *r = sraw + pix * CI + NB;         // [landmarks | cls]
+        const float *q = sd + pix * 4;
         float v;
         if (c < 4) {
-            const float x1 = (ax - r[0]) * fs, y1 = (ay - r[1]) * fs, x2 = (ax + r[2]) * fs, y2 = (ay + r[3]) * fs;
+            const float x1 = (ax - q[0]) * fs, y1 = (ay - q[1]) * fs, x2 = (ax + q[2]) * fs, y2 = (ay + q[3]) * fs;
             if (p.out_cxcywh)
                 v = c == 0 ? (x1 + x2) / 2.0f : (c == 1 ? (y1 + y2) / 2.0f : (c == 2 ? x2 - x1 : y2 - y1));
             else
@@ -216,9 +237,9 @@ __global__ __launch_bounds__(256) void decode_ltrb_kernel(LtrbParams p)
             v = 1.0f;
         } else if (c < 5 + 2 * p.P) {
             const int k = c - 5;
-            v = (r[4 + k] + ((k & 1) ? ay : ax)) * fs;
+            v = (r[k] + ((k & 1) ? ay : ax)) * fs;
         } else {
-            v = 1.0f / (1.0f + expf(-r[c - 1]));
+            v = 1.0f / (1.0f + expf(-r[c - 5]));
         }
         sout[i] = v;
     }
@@ -322,16 +343,17 @@ extern "C" int yamd_decode_dfl_unit_conf(const float *const *raw_host_ptrs, cons
     return decode_dfl_impl(raw_host_ptrs, hs, ws, strides, n_levels, batch, bins, nc, out_cxcywh, 1, out, stream);
 }
 
-extern "C" int yamd_decode_ltrb_points(const float *const *raw_host_ptrs, const int *hs, const int *ws, const int *strides,
-                                       int n_levels, int batch, int point_num, int nc, int out_cxcywh, float *out,
-                                       void *stream)
+static int decode_ltrb_impl(const float *const *raw_host_ptrs, const int *hs, const int *ws, const int *strides,
+                            int n_levels, int batch, int bins, int point_num, int nc, int out_cxcywh, float *out,
+                            void *stream)
 {
     YAMD_REQUIRE(raw_host_ptrs && hs && ws && strides && out, "null argument");
-    YAMD_REQUIRE(n_levels > 0 && n_levels <= 8 && batch > 0 && batch <= 65535 && point_num >= 0 && nc > 0, "bad shape");
+    YAMD_REQUIRE(n_levels > 0 && n_levels <= 8 && batch > 0 && batch <= 65535 && point_num >= 0 && nc > 0 && bins >= 1,
+                 "bad shape");
     long long rows = 0;
     for (int i = 0; i < n_levels; ++i) rows += (long long)hs[i] * ws[i];
-    const size_t lds = (size_t)DPIX * (4 + 2 * point_num + nc + 5 + 2 * point_num + nc) * sizeof(float);
-    YAMD_REQUIRE(lds <= 64 * 1024, "point_num/nc too large for the decode tile");
+    const size_t lds = (size_t)DPIX * (4 * bins + 2 * point_num + nc + 5 + 2 * point_num + nc + 4) * sizeof(float);
+    YAMD_REQUIRE(lds <= 64 * 1024, "bins/point_num/nc too large for the decode tile");
     long long off = 0;
     for (int i = 0; i < n_levels; ++i) {
         YAMD_REQUIRE(raw_host_ptrs[i] != nullptr && hs[i] > 0 && ws[i] > 0 && strides[i] > 0, "bad level %d", i);
@@ -344,6 +366,7 @@ extern "C" int yamd_decode_ltrb_points(const float *const *raw_host_ptrs, const 
         p.nc = nc;
         p.stride = strides[i];
         p.out_cxcywh = out_cxcywh ? 1 : 0;
+        p.bins = bins;
         p.rows_per_image = rows;
         p.row_offset = off;
         hipLaunchKernelGGL(decode_ltrb_kernel, dim3(ceil_div((long long)hs[i] * ws[i], DPIX), batch), dim3(256), lds,
@@ -352,4 +375,19 @@ extern "C" int yamd_decode_ltrb_points(const float *const *raw_host_ptrs, const 
         off += (long long)hs[i] * ws[i];
     }
     return YAMD_OK;
+}
+
+extern "C" int yamd_decode_ltrb_points(const float *const *raw_host_ptrs, const int *hs, const int *ws, const int *strides,
+                                       int n_levels, int batch, int point_num, int nc, int out_cxcywh, float *out,
+                                       void *stream)
+{
+    return decode_ltrb_impl(raw_host_ptrs, hs, ws, strides, n_levels, batch, 1, point_num, nc, out_cxcywh, out, stream);
+}
+
+extern "C" int yamd_decode_dfl_points(const float *const *raw_host_ptrs, const int *hs, const int *ws, const int *strides,
+                                      int n_levels, int batch, int bins, int point_num, int nc, int out_cxcywh, float *out,
+                                      void *stream)
+{
+    YAMD_REQUIRE(bins >= 2, "bins=%d: a DFL head has at least two bins per side", bins);
+    return decode_ltrb_impl(raw_host_ptrs, hs, ws, strides, n_levels, batch, bins, point_num, nc, out_cxcywh, out, stream);
 }

@@ -51,6 +51,13 @@ def registry() -> Dict[str, Dict[str, Any]]:
                                      ".cv3.block.bn.weight": 0.5})),
         "v6l": dict(cls=YoloV6, param=lambda: _param.Yolo6Param(m_type="l"),
                     init=dict(scale={"reg_predict_list": 2.0, ".alpha": 0.6, ".cv3.block.bn.weight": 0.5})),
+        "v6facem": dict(cls=YoloV6Face, param=lambda: _param.Yolo6FaceParam(m_type="m"),
+                        init=dict(scale={".rbr_dense.bn.weight": 0.55, ".rbr_1x1.bn.weight": 0.55,
+                                         ".rbr_identity.weight": 0.55, "reg_predict_list": 2.0, ".alpha": 0.6,
+                                         ".cv3.block.bn.weight": 0.5, "reg_point_predict_list": 0.3})),
+        "v6posel": dict(cls=YoloV6Pose, param=lambda: _param.Yolo6PoseParam(m_type="l"),
+                        init=dict(scale={"reg_predict_list": 2.0, ".alpha": 0.6, ".cv3.block.bn.weight": 0.5,
+                                         "reg_point_predict_list": 0.3})),
         "v6pose": dict(cls=YoloV6Pose, param=lambda: _param.Yolo6PoseParam(m_type="s"),
                        init=dict(scale={".rbr_dense.bn.weight": 0.55, ".rbr_1x1.bn.weight": 0.55,
                                         ".rbr_identity.weight": 0.55, "reg_predict_list": 0.3,

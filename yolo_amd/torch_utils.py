@@ -153,9 +153,10 @@ def decode_dfl(raws: List[torch.Tensor], strides, reg_max: int, nc: int, out_fmt
     return out
 
 
-def decode_ltrb_points(raws: List[torch.Tensor], strides, point_num: int, nc: int, out_fmt: str) -> torch.Tensor:
-    """raws[i]: (B,h,w,4+2P+nc) float32 NHWC [ltrb | landmarks | cls].  Returns (B, A, 5+2P+nc):
-    [box, 1.0, landmarks, scores] (luoyang/yolov6_face/YoloV6Face.py:42-58 and :66-74)."""
+def decode_ltrb_points(raws: List[torch.Tensor], strides, point_num: int, nc: int, out_fmt: str, bins: int = 1
+                       ) -> torch.Tensor:
+    """raws[i]: (B,h,w,4*bins+2P+nc) float32 NHWC [ltrb (bins > 1: 4 x bins DFL logits) | landmarks | cls].  Returns
+    (B, A, 5+2P+nc): [box, 1.0, landmarks, scores] (luoyang/yolov6_face/YoloV6Face.py:42-58 and :66-74)."""
     B = raws[0].shape[0]
     n = len(raws)
     for r in raws:
@@ -166,8 +167,13 @@ def decode_ltrb_points(raws: List[torch.Tensor], strides, point_num: int, nc: in
     hs = (ctypes.c_int * n)(*[r.shape[1] for r in raws])
     ws = (ctypes.c_int * n)(*[r.shape[2] for r in raws])
     ss = (ctypes.c_int * n)(*[int(s) for s in strides])
-    _lib.check(LIB.yamd_decode_ltrb_points(ptrs, hs, ws, ss, n, B, point_num, nc, 1 if out_fmt == "cxcywh" else 0,
-                                           out.data_ptr(), _lib.current_stream()), "decode_ltrb_points")
+    cx = 1 if out_fmt == "cxcywh" else 0
+    if bins > 1:
+        _lib.check(LIB.yamd_decode_dfl_points(ptrs, hs, ws, ss, n, B, bins, point_num, nc, cx, out.data_ptr(),
+                                              _lib.current_stream()), "decode_dfl_points")
+    else:
+        _lib.check(LIB.yamd_decode_ltrb_points(ptrs, hs, ws, ss, n, B, point_num, nc, cx, out.data_ptr(),
+                                               _lib.current_stream()), "decode_ltrb_points")
     return out
 
 

@@ -7,10 +7,10 @@ and the module tree of luoyang/yolov6_face/YoloV6FaceBody.py (ConvModule :98-134
 create_head :1070-1182, YoloV6FaceHead :1230-1455), so ``state_dict`` keys are identical before and after ``fuse()``.
 Every BatchNorm runs with eps 1e-3 (YoloV6FaceBody.py:1479-1486).  RepVGG blocks are re-parameterised to a single
 3x3 conv + ReLU when the plan is compiled; ConvTranspose2d(2,2) runs as a 1x1 conv + depth-to-space.
-The detect model also comes as m/l (``YoloV6`` only): CSPBepBackboneP6 / CSPRepBiFPANNeckP6 of luoyang/yolov6/YoloV6Body.py
+The three models also come as m/l: CSPBepBackboneP6 / CSPRepBiFPANNeckP6 of luoyang/yolov6/YoloV6Body.py
 (:811-906, :909-1022) made of BepC3 (:719-739) over BottleRep pairs with a learned shortcut weight (:427-472), SimSPPF /
-SPPF (:321-369) and a 17-bin DFL box head (:1322-1343); m uses RepVGG blocks + ReLU, l uses conv + SiLU (:1185-1188).
-The face and pose m/l variants are not built.
+SPPF (:321-369) and a 17-bin DFL box head (:1322-1343); m uses RepVGG blocks + ReLU, l uses conv + SiLU (:1185-1188);
+the face and pose bodies (luoyang/yolov6_face/YoloV6FaceBody.py, luoyang/yolov6_pose/YoloV6PoseBody.py) repeat these classes.
 """
 import math
 from typing import Any, Dict, List
@@ -137,8 +137,6 @@ def _tree(param) -> nn.Module:
     if param.m_type not in _CFG:
         raise NotImplementedError(f"YoloV6 m_type={param.m_type!r} is not built on the HIP path")
     csp = param.m_type in _CSP_E
-    if csp and getattr(param, "point_num", 0):
-        raise NotImplementedError(f"m_type={param.m_type!r}: only the detect model is built as m/l; face and pose are n/s")
     dm, wm = _CFG[param.m_type]
     rep = [(max(round(i * dm), 1) if i > 1 else i) for i in (_BACKBONE[0] + _NECK[0])]
     ch = [math.ceil(i * wm / 8) * 8 for i in (_BACKBONE[1] + _NECK[1])]
@@ -339,10 +337,12 @@ class YoloV6Face(TaskModel):
         return [out[f"L{i}"] for i in range(self.param.num_layers)]
 
     def _decode(self, raws, fmt: str) -> torch.Tensor:
-        if self.box_channels != 4:
+        dfl = self.box_channels != 4
+        if dfl and not self.point_num:
             return torch_utils.decode_dfl(raws, self.param.strides, DFL_BINS, self.param.class_num, fmt, unit_conf=True)
         ncp = self.param.class_num + (self.point_num if self.point_conf else 0)
-        return torch_utils.decode_ltrb_points(raws, self.param.strides, self.point_num, ncp, fmt)
+        return torch_utils.decode_ltrb_points(raws, self.param.strides, self.point_num, ncp, fmt,
+                                              bins=DFL_BINS if dfl else 1)
 
     def _forward(self, images: torch.Tensor) -> List[torch.Tensor]:
         """[(B, A, 5+2P+nc)]: cxcywh, 1.0, landmarks, class scores (YoloV6Face.py:42-58)."""
@@ -415,7 +415,7 @@ class YoloV6(YoloV6Face):
 
 
 class YoloV6Pose(YoloV6Face):
-    """``YoloV6Pose(param)`` (n/s): the face graph with one confidence per keypoint, which the reference takes from the
+    """``YoloV6Pose(param)``: the face graph with one confidence per keypoint, which the reference takes from the
     class-prediction conv (``class_num + point_num`` outputs, luoyang/yolov6_pose/YoloV6PoseBody.py:1412-1430);
     ``_forward`` / ``predict`` as luoyang/yolov6_pose/YoloV6Pose.py:43-89.
     ``predicts`` rows: [x1,y1,x2,y2, 1.0, cls_conf, 17 x (x,y), 17 confidences, cls_id]."""
