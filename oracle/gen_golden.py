@@ -287,6 +287,7 @@ def _ref_models():
         "v6pose": (_lazy("luoyang.yolov6_pose.YoloV6Pose", "YoloV6Pose"), lambda: _lazy("luoyang.param.Param", "Yolo6PoseParam")(m_type="s"),
                    "v6", 6 + 3 * 17 + 1, 128),
         "v7": (_lazy("luoyang.yolov7.YoloV7", "YoloV7"), lambda: _lazy("luoyang.param.Param", "Yolo7Param")(m_type="l"), "desc", 7, 64),
+        "v7x": (_lazy("luoyang.yolov7.YoloV7", "YoloV7"), lambda: _lazy("luoyang.param.Param", "Yolo7Param")(m_type="x"), "desc", 7, 64),
         "v7face": (_lazy("luoyang.yolov7_face.YoloV7Face", "YoloV7Face"), lambda: _lazy("luoyang.param.Param", "Yolo7FaceParam")(m_type="l"),
                    "desc", 6 + 2 * 5 + 1, 64),
         "v5face": (_lazy("luoyang.yolov5_face.YoloV5Face", "YoloV5Face"), lambda: _lazy("luoyang.param.Param", "Yolo5FaceParam")(m_type="s"),

@@ -218,8 +218,10 @@ def _v7_rep(sd, p, x):
     return silu(y)
 
 
-def v7pose_body(sd: SD, images: torch.Tensor, phi: str = "l") -> List[torch.Tensor]:
-    """images (B,3,S,S) -> raw heads [stride 8, 16, 32], each (B, 3*(5+3P+nc), h, w)."""
+def v7pose_body(sd: SD, images: torch.Tensor) -> List[torch.Tensor]:
+    """images (B,3,S,S) -> raw heads [stride 8, 16, 32], each (B, 3*(5+3P+nc), h, w).  The width (l: 32 base channels,
+    x: 40) decides which branch outputs the concat blocks gather (YoloV7PoseBody.py:416-421)."""
+    phi = {32: "l", 40: "x"}[sd["body_net.backbone.stem.0.conv.weight"].shape[0]]
     bids = {"l": [-1, -3, -5, -6], "x": [-1, -3, -5, -7, -8]}[phi]
     nids = {"l": [-1, -2, -3, -4, -5, -6], "x": [-1, -3, -5, -7, -8]}[phi]
     b, n = "body_net.backbone.", "body_net."
@@ -417,7 +419,7 @@ def model_ref(name: str):
                     decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "pose",
                                                                              point_num=p.point_num, clamp_points=predict),
                     nms=dict(in_fmt="cxcywh", point_num=17, point_conf=True))
-    if name == "v7":
+    if name in ("v7", "v7x"):
         return dict(body=v7pose_body,
                     decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "v5"),
                     nms=dict(in_fmt="cxcywh"))

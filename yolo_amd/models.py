@@ -37,6 +37,7 @@ def registry() -> Dict[str, Dict[str, Any]]:
                                     "yolo_head2.1.weight": 0.05, "yolo_head3.1.weight": 0.05})),
         "v7pose": dict(cls=YoloV7Pose, param=lambda: _param.Yolo7PoseParam(m_type="l"), init={}),
         "v7": dict(cls=YoloV7, param=lambda: _param.Yolo7Param(m_type="l"), init={}),
+        "v7x": dict(cls=YoloV7, param=lambda: _param.Yolo7Param(m_type="x"), init={}),
         "v7face": dict(cls=YoloV7Face, param=lambda: _param.Yolo7FaceParam(m_type="l"), init={}),
         # RepVGG blocks sum three un-normalised branches ~40 times in a row: scale the branch BatchNorms so that the
         # sum keeps the activation variance; box/landmark logits (grid units, multiplied by the stride) get a std near 1

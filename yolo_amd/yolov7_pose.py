@@ -4,7 +4,8 @@ Mirrors luoyang/yolov7_pose/YoloV7Pose.py (``_forward`` :57-83, ``predict`` :132
 tree of luoyang/yolov7_pose/YoloV7PoseBody.py (Conv :24-48, MultiConcatBlock :51-73, MP/TransitionBlock :76-100,
 Backbone :103-148, SppCspC :175-192, RepConv :195-380, YoloV7PoseBody :402-509), so ``state_dict`` keys are identical
 before and after ``fuse()``.  RepConv (3x3+BN, 1x1+BN and optional identity BN branches) is re-parameterised into
-one 3x3 conv with bias when the plan is compiled.
+one 3x3 conv with bias when the plan is compiled.  Both widths of the reference are built: l, and x (40-channel base
+width, five-way concats, plain convs in place of RepConv, :402-478).
 """
 from typing import List, Optional
 
@@ -15,7 +16,7 @@ import torch.nn.functional as F
 from . import lib as _lib
 from . import torch_utils
 from .engine import Program, View
-from .graph import AnchorTaskModel, Recorder, conv_bn
+from .graph import AnchorTaskModel, Recorder, conv_bn, folded
 from .param import Yolo7PoseParam
 from .yolov3 import _seq
 
@@ -76,9 +77,8 @@ def rep_conv_equivalent(m: nn.Module):
 
 def _tree(param, anchor_num: int, cols: int) -> nn.Module:
     phi = param.m_type
-    if phi != "l":
-        raise NotImplementedError(f"YOLOv7 m_type={phi!r}: only the l width is built on the HIP path (the x width has "
-                                  "40-channel layers, for which no conv tiling exists)")
+    if phi not in ("l", "x"):
+        raise NotImplementedError(f"YOLOv7 m_type={phi!r}: the reference defines the l and x widths")
     tc = {"l": 32, "x": 40}[phi]
     bc = 32
     pc = {"l": 32, "x": 64}[phi]
@@ -156,7 +156,14 @@ class YoloV7Pose(AnchorTaskModel):
         R = Recorder(P, _lib.ACT_SILU)
         x = P.image16(3)
         for i in range(3):
-            x = R.cba(f"stem.{i}", bb.stem[i], x)
+            w, b, st = folded(bb.stem[i])
+            # the x width starts with 40 channels; activations are stored in multiples of 16, so that layer computes 8
+            # more output channels with zero weights and zero bias (SiLU(0) = 0) and the next one ignores them
+            cin_pad, cout_pad = x.c - w.shape[1] if i else 0, -w.shape[0] % 16
+            if cin_pad or cout_pad:
+                w = F.pad(w, [0, 0, 0, 0, 0, cin_pad, 0, cout_pad])
+                b = F.pad(b, [0, cout_pad])
+            x = P.conv(f"stem.{i}", x, w, b, st, R.act)
         x = self._mcb(R, "dark2.1", bb.dark2[1], R.cba("dark2.0", bb.dark2[0], x))
         feat1 = self._mcb(R, "dark3.1", bb.dark3[1], self._transition(R, "dark3.0", bb.dark3[0], x))
         feat2 = self._mcb(R, "dark4.1", bb.dark4[1], self._transition(R, "dark4.0", bb.dark4[0], feat1))
