@@ -86,7 +86,7 @@ def max_over_ranks(value: float, world: int, dry: bool) -> float:
 DEFAULT_BATCH = {"v5s": 256, "v8s": 128, "v7pose": 512, "v6face": 512, "v3": 256, "v4": 256,
                  # variants outside the benchmark configurations: the batch of the nearest configuration
                  "v5face": 256, "v5pose": 256, "v7": 256, "v7face": 256, "v6": 256, "v6pose": 256,
-                 "v5m": 128, "v8m": 64, "v8n": 128, "v6facen": 512, "v6m": 64, "v6l": 32, "v6facem": 64, "v6posel": 32, "v7x": 64}
+                 "v5m": 128, "v8m": 64, "v8n": 128, "v6facen": 512, "v6m": 64, "v6l": 32, "v6facem": 64, "v6posel": 32, "v7x": 64, "v5facem": 128, "v5posex": 32}
 LABEL = {"v5s": "YOLOv5s VOC-20 detect", "v8s": "YOLOv8s VOC-20 detect", "v7pose": "YOLOv7-l pose (17 keypoints)",
          "v6face": "YOLOv6-s face (5 landmarks, 4 levels)", "v3": "YOLOv3 VOC-20 detect", "v4": "YOLOv4 VOC-20 detect",
          "v5face": "YOLOv5s face (5 landmarks)", "v5pose": "YOLOv5s pose (17 keypoints)", "v7": "YOLOv7-l VOC-20 detect",
@@ -94,7 +94,8 @@ LABEL = {"v5s": "YOLOv5s VOC-20 detect", "v8s": "YOLOv8s VOC-20 detect", "v7pose
          "v6pose": "YOLOv6-s pose (17 keypoints, 4 levels)", "v5m": "YOLOv5m VOC-20 detect", "v8m": "YOLOv8m VOC-20 detect",
          "v8n": "YOLOv8n VOC-20 detect", "v6facen": "YOLOv6-n face (5 landmarks, 4 levels)",
          "v6m": "YOLOv6-m VOC-20 detect (4 levels, DFL)", "v6l": "YOLOv6-l VOC-20 detect (4 levels, DFL)", "v6facem": "YOLOv6-m face (5 landmarks, 4 levels, DFL)",
-         "v6posel": "YOLOv6-l pose (17 keypoints, 4 levels, DFL)", "v7x": "YOLOv7-x VOC-20 detect"}
+         "v6posel": "YOLOv6-l pose (17 keypoints, 4 levels, DFL)", "v7x": "YOLOv7-x VOC-20 detect", "v5facem": "YOLOv5m face (5 landmarks)",
+         "v5posex": "YOLOv5x pose (17 keypoints)"}
 
 
 def build_model(name: str, weights: str):

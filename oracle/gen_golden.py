@@ -292,6 +292,10 @@ def _ref_models():
                    "desc", 6 + 2 * 5 + 1, 64),
         "v5face": (_lazy("luoyang.yolov5_face.YoloV5Face", "YoloV5Face"), lambda: _lazy("luoyang.param.Param", "Yolo5FaceParam")(m_type="s"),
                    "desc", 6 + 2 * 5 + 1, 64),
+        "v5facem": (_lazy("luoyang.yolov5_face.YoloV5Face", "YoloV5Face"), lambda: _lazy("luoyang.param.Param", "Yolo5FaceParam")(m_type="m"),
+                    "desc", 6 + 2 * 5 + 1, 64),
+        "v5posex": (_lazy("luoyang.yolov5_pose.YoloV5Pose", "YoloV5Pose"), lambda: _lazy("luoyang.param.Param", "Yolo5PoseParam")(m_type="x"),
+                    "desc", 6 + 3 * 17 + 1, 64),
         "v5pose": (_lazy("luoyang.yolov5_pose.YoloV5Pose", "YoloV5Pose"), lambda: _lazy("luoyang.param.Param", "Yolo5PoseParam")(m_type="s"),
                    "desc", 6 + 3 * 17 + 1, 64),
     }

@@ -428,12 +428,12 @@ def model_ref(name: str):
                     decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "face",
                                                                              point_num=p.point_num, clamp_points=predict),
                     nms=dict(in_fmt="cxcywh", point_num=5, point_conf=False))
-    if name == "v5face":
+    if name in ("v5face", "v5facem"):
         return dict(body=v5_ref.face_body_forward,
                     decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "face",
                                                                              point_num=p.point_num, clamp_points=predict),
                     nms=dict(in_fmt="cxcywh", point_num=5, point_conf=False))
-    if name == "v5pose":
+    if name in ("v5pose", "v5posex"):
         return dict(body=v5_ref.face_body_forward,
                     decode=lambda raws, p, predict: decode_ref.decode_anchor(raws, p.anchors, p.strides, p.img_size, "pose",
                                                                              point_num=p.point_num, clamp_points=predict),

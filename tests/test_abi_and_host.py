@@ -126,7 +126,7 @@ def test_checkpoint_architecture_detection(tmp_path):
     from yolo_amd import models
     from yolo_amd.init import seeded_state_dict
     for name in ("v5s", "v8s", "v4", "v7pose", "v6face", "v5face", "v5pose", "v7", "v7face", "v6", "v6pose", "v5m", "v8m", "v8n",
-                 "v6facen", "v6m", "v6l", "v6facem", "v6posel", "v7x"):
+                 "v6facen", "v6m", "v6l", "v6facem", "v6posel", "v7x", "v5facem", "v5posex"):
         size = 128 if name.startswith("v6") else 64
         p, m = models.create(name, size)
         sd = seeded_state_dict(m, seed=2, mode="spread", **models.init_options(name))

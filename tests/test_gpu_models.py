@@ -18,9 +18,9 @@ from test_gpu_v5_e2e import _check_pred, _match_rows, _rel_l2
 
 pytestmark = pytest.mark.gpu
 
-NAMES = ["v8s", "v3", "v4", "v7pose", "v6face", "v5face", "v5pose", "v7", "v7face", "v6", "v6pose", "v5m", "v8m", "v8n", "v6facen", "v6m", "v6l", "v6facem", "v6posel", "v7x"]
+NAMES = ["v8s", "v3", "v4", "v7pose", "v6face", "v5face", "v5pose", "v7", "v7face", "v6", "v6pose", "v5m", "v8m", "v8n", "v6facen", "v6m", "v6l", "v6facem", "v6posel", "v7x", "v5facem", "v5posex"]
 EXP_WH = ("v3", "v4")
-POINTS = {"v7pose": 17, "v6face": 5, "v5face": 5, "v5pose": 17, "v7face": 5, "v6pose": 17, "v6facen": 5, "v6facem": 5, "v6posel": 17}
+POINTS = {"v7pose": 17, "v6face": 5, "v5face": 5, "v5pose": 17, "v7face": 5, "v6pose": 17, "v6facen": 5, "v6facem": 5, "v6posel": 17, "v5facem": 5, "v5posex": 17}
 
 
 def _row_stride(name, p, size):
@@ -29,7 +29,7 @@ def _row_stride(name, p, size):
     (2 sigmoid)^2 x anchor), whose random-init graph reaches the heads with a logit error of a few 1e-2"""
     if name in ("v6face", "v6", "v6pose", "v6facen", "v6m", "v6l", "v6facem", "v6posel"):
         return np.concatenate([np.full((size // s) ** 2, s, np.float32) for s in p.strides])
-    if name in ("v5face", "v5pose", "v7face"):
+    if name in ("v5face", "v5pose", "v7face", "v5facem", "v5posex"):
         out = []
         for lvl, s in enumerate(p.strides):
             for aw, ah in p.anchors[3 * lvl:3 * lvl + 3]:
@@ -170,7 +170,7 @@ def test_yolo_predict_entry_points(gpu_device, tmp_path):
 
 
 FULL = {"v8s": 128, "v3": 256, "v4": 256, "v7pose": 512, "v6face": 512,     # benchmark per-GPU batch sizes
-        "v5face": 256, "v5pose": 256, "v7": 256, "v7face": 256, "v6": 256, "v6pose": 256, "v5m": 128, "v8m": 64, "v8n": 128, "v6facen": 256, "v6m": 64, "v6l": 32, "v6facem": 64, "v6posel": 32, "v7x": 64}               # (variants: the v5s batch)
+        "v5face": 256, "v5pose": 256, "v7": 256, "v7face": 256, "v6": 256, "v6pose": 256, "v5m": 128, "v8m": 64, "v8n": 128, "v6facen": 256, "v6m": 64, "v6l": 32, "v6facem": 64, "v6posel": 32, "v7x": 64, "v5facem": 128, "v5posex": 32}               # (variants: the v5s batch)
 
 
 @pytest.mark.parametrize("name", NAMES)

@@ -11,7 +11,7 @@ from oracle import graphs_ref, postprocess
 from yolo_amd import models
 from yolo_amd.init import seeded_images, seeded_state_dict
 
-NAMES = ["v8s", "v3", "v4", "v7pose", "v6face", "v5face", "v5pose", "v7", "v7face", "v6", "v6pose", "v5m", "v8m", "v8n", "v6facen", "v6m", "v6l", "v6facem", "v6posel", "v7x"]
+NAMES = ["v8s", "v3", "v4", "v7pose", "v6face", "v5face", "v5pose", "v7", "v7face", "v6", "v6pose", "v5m", "v8m", "v8n", "v6facen", "v6m", "v6l", "v6facem", "v6posel", "v7x", "v5facem", "v5posex"]
 
 
 def _setup(name, which):

@@ -19,6 +19,11 @@ def registry() -> Dict[str, Dict[str, Any]]:
         # so that the logits stay in the range of a trained network
         "v5face": dict(cls=YoloV5Face, param=lambda: _param.Yolo5FaceParam(m_type="s"), init=dict(scale={"yolo_head_P": 0.1})),
         "v5pose": dict(cls=YoloV5Pose, param=lambda: _param.Yolo5PoseParam(m_type="s"), init=dict(scale={"yolo_head_P": 0.1})),
+        # m / x widths of the same graphs (24- and 40-channel stem conv); bottleneck damping as for v5m below
+        "v5facem": dict(cls=YoloV5Face, param=lambda: _param.Yolo5FaceParam(m_type="m"),
+                        init=dict(scale={f"m.{i}.cv2.bn.weight": 0.5 for i in range(6)})),
+        "v5posex": dict(cls=YoloV5Pose, param=lambda: _param.Yolo5PoseParam(m_type="x"),
+                        init=dict(scale={f"m.{i}.cv2.bn.weight": 0.5 for i in range(12)})),
         "v5s": dict(cls=YoloV5, param=lambda: _param.Yolo5Param(m_type="s").set_img_size(640), init={}),
         "v8s": dict(cls=YoloV8, param=lambda: _param.Yolo8Param(m_type="s"), init={}),
         # other widths of the two benchmark families (channel counts that are multiples of 16 but not of 32)

@@ -8,6 +8,7 @@ part of the ``state_dict``.  Heads decode as luoyang/yolov5_face/YoloV5FaceHead.
 anchor) and luoyang/yolov5_pose/YoloV5PoseHead.py:25-81 (keypoints ``2t - 0.5 + grid``, one confidence each).
 """
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import lib as _lib
 from .engine import Program
@@ -75,7 +76,16 @@ class _V5PointModel(AnchorTaskModel):
         cat_stem = P.buffer(s4, s4, 2 * bc, name="cat_stem")          # [stem_2b | stem_2p]
 
         s1 = B.cbs("stem.stem_1", bb.stem.stem_1, P.image16(3))
-        B.cbs("stem.stem_2b", bb.stem.stem_2b, B.cbs("stem.stem_2a", bb.stem.stem_2a, s1), out=cat_stem.slice(0, bc))
+        if (bc // 2) % 16:
+            # m / x widths: stem_2a has 24 / 40 outputs; activations are stored in multiples of 16 channels, so it
+            # computes the missing ones with zero weights and zero bias (SiLU(0) = 0) and stem_2b ignores them
+            pad = -(bc // 2) % 16
+            wa, ba = B._folded(bb.stem.stem_2a)
+            wb, bb_ = B._folded(bb.stem.stem_2b)
+            t = P.conv("stem.stem_2a", s1, F.pad(wa, [0, 0, 0, 0, 0, 0, 0, pad]), F.pad(ba, [0, pad]), 1, _lib.ACT_SILU)
+            P.conv("stem.stem_2b", t, F.pad(wb, [0, 0, 0, 0, 0, pad]), bb_, 2, _lib.ACT_SILU, out=cat_stem.slice(0, bc))
+        else:
+            B.cbs("stem.stem_2b", bb.stem.stem_2b, B.cbs("stem.stem_2a", bb.stem.stem_2a, s1), out=cat_stem.slice(0, bc))
         P.maxpool2(s1, cat_stem.slice(bc, bc))
         x = B.cbs("stem.stem_3", bb.stem.stem_3, cat_stem)
         x = B.c3("dark2.0", bb.dark2[0], x, True)
