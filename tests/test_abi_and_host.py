@@ -141,3 +141,25 @@ def test_checkpoint_architecture_detection(tmp_path):
             m.fuse()
             p3, m3 = models.from_state_dict(m.state_dict(), size)
             assert list(m3.state_dict().keys()) == list(m.state_dict().keys())
+
+
+def test_every_family_and_width_compiles():
+    """Every (model class, m_type) pair the reference's Param classes accept compiles into a plan (host side only: BN
+    folding, re-parameterisation, tiling choice and weight packing; no GPU work)."""
+    from yolo_amd import param as P
+    from yolo_amd.yolov5 import YoloV5
+    from yolo_amd.yolov5_face import YoloV5Face, YoloV5Pose
+    from yolo_amd.yolov6_face import YoloV6, YoloV6Face, YoloV6Pose
+    from yolo_amd.yolov7 import YoloV7, YoloV7Face
+    from yolo_amd.yolov7_pose import YoloV7Pose
+    from yolo_amd.yolov8 import YoloV8
+    combos = [(YoloV5, P.Yolo5Param, "smlx"), (YoloV8, P.Yolo8Param, "nsmlx"), (YoloV5Face, P.Yolo5FaceParam, "smlx"),
+              (YoloV5Pose, P.Yolo5PoseParam, "smlx"), (YoloV6, P.Yolo6Param, "nsml"), (YoloV6Face, P.Yolo6FaceParam, "nsml"),
+              (YoloV6Pose, P.Yolo6PoseParam, "nsml"), (YoloV7, P.Yolo7Param, "lx"), (YoloV7Face, P.Yolo7FaceParam, "lx"),
+              (YoloV7Pose, P.Yolo7PoseParam, "lx")]
+    for cls, mk, types in combos:
+        for t in types:
+            p = mk(m_type=t)
+            p.set_img_size(128)
+            prog = cls(p).program()
+            assert len(prog.convs) > 40 and len(prog.outputs) == len(p.strides), (cls.__name__, t)
