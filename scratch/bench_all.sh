@@ -1,7 +1,7 @@
 #!/bin/bash
 # bench.py for every model of the registry, one JSON line each (no CPU baseline): usage scratch/bench_all.sh out.txt
 out=$1; : > $out
-for m in v5s v8s v3 v4 v7pose v6face v5face v5pose v7 v7face v6 v6pose v5m v8m v8n v6facen v6m v6l v6facem v6posel v7x; do
+for m in v5s v8s v3 v4 v7pose v6face v5face v5pose v7 v7face v6 v6pose v5m v8m v8n v6facen v6m v6l v6facem v6posel v7x v5facem v5posex; do
   timeout -k 10 240 python bench.py --model $m --steps 8 --warmup 3 --no-cpu-baseline > /tmp/b_$m.json 2> /tmp/b_$m.err || { echo "$m FAILED" >> $out; tail -3 /tmp/b_$m.err >> $out; exit 1; }
   python - $m <<'PY' >> $out
 import json, sys
