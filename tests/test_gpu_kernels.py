@@ -145,6 +145,22 @@ def test_conv_weighted_residual(gpu_device, k, cin, cout, H, W, act, alpha):
     assert float(err.abs().max()) <= 1.5e-2 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(128, 75, 80, 80), (64, 75, 24, 20), (64, 21, 13, 40), (64, 75, 19, 19),
+                                          (32, 171, 16, 36)])
+def test_conv_f32_dense_output(gpu_device, cin, cout, H, W):
+    """Raw head logits written densely (pixel stride == cout): the flat store path, with 16-byte stores when the
+    width is a multiple of 4 and scalar stores otherwise."""
+    g = torch.Generator().manual_seed(cin + cout + H + W)
+    x = _bf16_round(torch.randn((3, cin, H, W), generator=g))
+    w = _bf16_round(torch.randn((cout, cin, 1, 1), generator=g) * (2.0 / cin) ** 0.5)
+    b = torch.randn((cout,), generator=g)
+    want = F.conv2d(x, w, b)
+    got = _run_conv(gpu_device, x, w, b, 1, 1, 0, None, True)
+    err = (got - want).double()
+    assert float(err.norm() / want.double().norm()) <= 1e-4
+    assert float(err.abs().max()) <= 1e-3 * float(want.abs().max())
+
+
 TILING_CASES = [
     # k, s, cin, cout, H, W, residual, (mrep, nrep, ck, nwaves): every tiling the per-layer tuner may pick
     (1, 1, 64, 128, 40, 40, True, (1, 4, 32, 4)),

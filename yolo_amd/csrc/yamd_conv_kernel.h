@@ -285,6 +285,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_kernel(Co
                 // boundaries (neighbouring pixels of a tile row are neighbours in memory)
                 const float inv = 1.0f / (float)nco;
                 const int total = 32 * nco;
+                // Tile rows start at multiples of 4 pixels (TW and the fragment size are multiples of 4), so when the
+                // image width is one too, every aligned group of 4 floats of the run lies inside one run of 4 pixels
+                // that are neighbours in memory and all inside or all outside the image: 16-byte stores.
+                if ((p.Wout & 3) == 0 && ((uintptr_t)p.y & 15) == 0) {
+                    for (int i = lane * 4; i < total; i += 256) {
+                        f32x4 v;
+                        int r0 = 0, c0 = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int r = (int)(((float)(i + j) + 0.5f) * inv);
+                            const int c = i + j - r * nco;
+                            if (j == 0) { r0 = r; c0 = c; }
+                            v[j] = *(const float *)(wreg + r * RSF + c * 4);
+                        }
+                        const int pq = wave * (32 * MREP) + m * 32 + r0;
+                        const int qr = pq / TW, qc = pq % TW;
+                        if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)
+                            *(f32x4 *)((float *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + c0) = v;
+                    }
+                } else
                 for (int i = lane; i < total; i += 64) {
                     const int r = (int)(((float)i + 0.5f) * inv);
                     const int c = i - r * nco;
