@@ -161,6 +161,22 @@ def test_conv_f32_dense_output(gpu_device, cin, cout, H, W):
     assert float(err.abs().max()) <= 1e-3 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("k,cin,cout,H,W,extra", [(1, 64, 20, 80, 80, 64), (1, 64, 64, 40, 40, 4), (1, 32, 4, 17, 23, 8),
+                                                  (1, 128, 132, 20, 20, 12), (1, 64, 20, 9, 7, 2)])
+def test_conv_f32_channel_slice(gpu_device, k, cin, cout, H, W, extra):
+    """fp32 logits written into a channel slice of a wider pixel (the anchor-free heads): 16-byte pieces when the slice
+    is aligned (extra % 4 == 0), scalar stores otherwise; the neighbouring channels stay untouched."""
+    g = torch.Generator().manual_seed(cin + cout + H + W + extra)
+    x = _bf16_round(torch.randn((2, cin, H, W), generator=g))
+    w = _bf16_round(torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+    b = torch.randn((cout,), generator=g)
+    want = F.conv2d(x, w, b, padding=k // 2)
+    got = _run_conv(gpu_device, x, w, b, k, 1, 0, None, True, out_extra=extra)
+    err = (got - want).double()
+    assert float(err.norm() / want.double().norm()) <= 1e-4
+    assert float(err.abs().max()) <= 1e-3 * float(want.abs().max())
+
+
 TILING_CASES = [
     # k, s, cin, cout, H, W, residual, (mrep, nrep, ck, nwaves): every tiling the per-layer tuner may pick
     (1, 1, 64, 128, 40, 40, True, (1, 4, 32, 4)),

@@ -314,6 +314,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_kernel(Co
                         ((float *)p.y)[((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + c] =
                             *(const float *)(wreg + r * RSF + c * 4);
                 }
+            } else if ((nco & 3) == 0 && (p.y_cs & 3) == 0 && ((uintptr_t)p.y & 15) == 0) {
+                // a channel slice of a wider pixel whose pieces are 16-byte aligned: every lane stores four channels
+                // of one pixel, consecutive lanes walk the channels of a pixel, then the next pixel
+                const int ppr = nco >> 2;
+                const float invp = 1.0f / (float)ppr;
+                for (int i = lane; i < 32 * ppr; i += 64) {
+                    const int r = (int)(((float)i + 0.5f) * invp);
+                    const int piece = i - r * ppr;
+                    const int pq = wave * (32 * MREP) + m * 32 + r;
+                    const int qr = pq / TW, qc = pq % TW;
+                    if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)
+                        *(f32x4 *)((float *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs +
+                                   nt * (NREP * 32) + piece * 4) = *(const f32x4 *)(wreg + r * RSF + piece * 16);
+                }
             } else {
                 for (int r = 0; r < 32; ++r) {
                     const int pq = wave * (32 * MREP) + m * 32 + r;
