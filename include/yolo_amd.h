@@ -42,6 +42,14 @@ extern "C" {
 const char *yamd_last_error(void);
 int yamd_version(void);
 
+/* Optional per-device set-up, for the device that is current on the calling thread: raises the dynamic-LDS limit of
+ * every kernel of the library that needs it.  Every entry point does this lazily for the kernels it launches (once per
+ * kernel and device, safe from several host threads), so the call is only needed where that lazy step is unwanted:
+ * before a region under HIP stream capture, or to take the one-off cost out of the first request.  Call it once per
+ * device, with that device current.  No counterpart in the reference (PyTorch initialises its kernels the same lazy
+ * way). */
+int yamd_init(void);
+
 /* ------------------------------------------------------------------------------------------
  * Conv + folded BatchNorm + activation (+ residual add) as one NHWC implicit-GEMM MFMA kernel.
  * Replaces nn.Conv2d -> nn.BatchNorm2d -> act of e.g. yolov5/YoloV5Body.py:26-51 (Conv.forward
@@ -60,6 +68,8 @@ typedef struct yamd_conv_desc {
     int32_t nwaves;           /* 4 or 8 wavefronts per workgroup (they share one staged weight tile) */
     float residual_scale;     /* y = act(..) + residual_scale * residual; yamd_conv_desc_init sets 1 (the learned
                                * shortcut weight ``alpha`` of BottleRep, yolov6/YoloV6Body.py:451-472) */
+    int32_t stages;           /* 1: one LDS image of the staged input chunk; 2: two, filled alternately (one barrier per
+                               * chunk instead of two) */
 } yamd_conv_desc;
 
 int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int cin, int cout, int act, int out_f32);
@@ -67,9 +77,9 @@ int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int cin, int c
 /* Optional: override the tiling chosen by yamd_conv_desc_init (per-layer tuning) before the weights are packed.
  * mrep in {1,2}: 128 or 256 output pixels per workgroup; nrep in {1,2,4}: 32*nrep output channels per workgroup;
  * ck in {16,32,64}: input channels staged per step; nwaves in {4,8}: wavefronts per workgroup, i.e. the pixel tile
- * is nwaves*32*mrep pixels.  Fails if that kernel is not built.  No counterpart in the reference (MIOpen picks its
- * own algorithm there). */
-int yamd_conv_desc_tune(yamd_conv_desc *d, int mrep, int nrep, int ck, int nwaves);
+ * is nwaves*32*mrep pixels; stages in {1,2}: LDS images of the staged chunk.  Fails if that kernel is not built.  No
+ * counterpart in the reference (MIOpen picks its own algorithm there). */
+int yamd_conv_desc_tune(yamd_conv_desc *d, int mrep, int nrep, int ck, int nwaves, int stages);
 
 /* Host-side: fold nothing, just reorder.  w_oihw_host is float [cout][cin_real][k][k] (BN already
  * folded by the caller, cf. utils/torch_utils.py:344-370), bias_host float[cout] or NULL.
@@ -249,6 +259,17 @@ int yamd_stem_pack_weights(int mode, const float *w_host, const float *bias_host
                            float *bias_packed_host);
 int yamd_stem_conv(int mode, const float *images, int batch, int h, int w, const void *w_packed,
                    const float *bias_packed, int cout, int act, void *y, int y_cstride, void *stream);
+
+/* ----------------------------------------------------------------------------------------
+ * Measurement helpers for the benchmark's roofline denominators; no counterpart in the reference and not on the
+ * detection path.
+ *   yamd_microbench_mfma_bf16: `blocks` workgroups of 4 wavefronts, each wavefront issues 4*iters
+ *       v_mfma_f32_32x32x16_bf16 (32768 FLOP each) on register operands taken from `operands` (4 KB of bf16, device);
+ *       `sink` receives blocks*256 floats.  FLOP = blocks * 4 * 4 * iters * 32768.
+ *   yamd_microbench_copy: dst[i] = src[i] with 16-byte accesses; bytes % 16 == 0.  Traffic = 2 * bytes.
+ * ---------------------------------------------------------------------------------------- */
+int yamd_microbench_mfma_bf16(const void *operands, float *sink, int blocks, int iters, void *stream);
+int yamd_microbench_copy(const void *src, void *dst, size_t bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,8 @@ reps = int(sys.argv[7]) if len(sys.argv) > 7 else 20
 d = L.ConvDesc()
 L.check(L.LIB.yamd_conv_desc_init(ctypes.byref(d), k, s, cin, cout, 1, 0))
 if len(sys.argv) > 11:
-    L.check(L.LIB.yamd_conv_desc_tune(ctypes.byref(d), *[int(v) for v in sys.argv[8:12]]))
+    t = [int(v) for v in sys.argv[8:13]]
+    L.check(L.LIB.yamd_conv_desc_tune(ctypes.byref(d), *(t + [1] * (5 - len(t)))))
 w = torch.randn(cout, cin, k, k) * 0.05
 b = torch.zeros(cout)
 wp = torch.empty(d.packed_w_elems, dtype=torch.int16); bp = torch.empty(d.cout_pad)

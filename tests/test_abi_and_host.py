@@ -163,3 +163,29 @@ def test_every_family_and_width_compiles():
             p.set_img_size(128)
             prog = cls(p).program()
             assert len(prog.convs) > 40 and len(prog.outputs) == len(p.strides), (cls.__name__, t)
+
+
+def test_plan_follows_weights_loaded_through_a_submodule():
+    """The compiled plan is keyed on the parameters themselves: loading weights into a submodule (the way the reference
+    loads a pretrained backbone), changing a tensor in place or changing the Param fields the plan reads all give a
+    new plan; an unchanged model keeps its plan."""
+    p = Yolo5Param(m_type="s").set_img_size(64)
+    m = YoloV5(p)
+    m.load_state_dict(seeded_state_dict(m, seed=1, mode="spread"))
+    prog = m.program()
+    assert m.program() is prog
+    first = prog.convs[0].w_host.clone() if prog.convs else None
+    other = seeded_state_dict(m, seed=2, mode="spread")
+    sub = {k[len("body_net."):]: v for k, v in other.items() if k.startswith("body_net.")}
+    m.body_net.load_state_dict(sub)
+    prog2 = m.program()
+    assert prog2 is not prog
+    assert not torch.equal(prog2.convs[0].w_host, first)
+    with torch.no_grad():
+        next(m.parameters()).mul_(0.5)
+    prog3 = m.program()
+    assert prog3 is not prog2
+    p.class_num = p.class_num            # same value: same plan
+    assert m.program() is prog3
+    p.anchors = [[a[0] + 1, a[1]] for a in p.anchors]
+    assert m.program() is not prog3

@@ -1,5 +1,6 @@
-"""world_size-2 rehearsal (gloo, CPU) of bench.py's multi-rank protocol: one process per rank, barrier on
-both sides of the timed region, MAX over ranks, one JSON line from rank 0."""
+"""world_size-2 rehearsals (gloo, CPU) of bench.py's multi-rank protocol: one process per rank, barrier on both sides
+of the timed region, MAX over ranks, one JSON line from rank 0 -- started by torch.distributed.run and started by
+bench.py itself (``--gpus 2`` without WORLD_SIZE), in weak and in strong scaling."""
 import json
 import os
 import subprocess
@@ -8,16 +9,32 @@ import sys
 from conftest import ROOT
 
 
+def _one_json_line(out):
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
 def test_bench_two_ranks_gloo():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--dry", "--backend", "gloo"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    rec = json.loads(lines[0])
+    rec = _one_json_line(subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT))
     assert rec["n_gpus"] == 2
     # rank 1 sleeps 0.10 s, rank 0 0.05 s: the reported time is the slowest rank's
     assert rec["elapsed_max"] >= 0.095
+    assert rec["scaling"] == "weak" and rec["images_per_rank"] == [256, 256] and rec["first_image_of_rank"] == [0, 256]
+
+
+def test_bench_starts_its_own_ranks_and_splits_a_global_batch():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry",
+           "--backend", "gloo", "--model", "v8s"]
+    rec = _one_json_line(subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT))
+    assert rec["n_gpus"] == 2 and rec["elapsed_max"] >= 0.095
+    assert rec["scaling"] == "strong" and rec["global_batch"] == 1024 and rec["images_per_rank"] == [512, 512]
+    cmd += ["--global-batch", "1023"]
+    rec = _one_json_line(subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT))
+    assert rec["images_per_rank"] == [512, 511] and rec["first_image_of_rank"] == [0, 512]

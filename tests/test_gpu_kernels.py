@@ -202,6 +202,29 @@ TILING_CASES = [
     (3, 2, 32, 64, 64, 64, False, (2, 2, 16, 8)),
     (3, 2, 32, 64, 23, 41, False, (2, 2, 16, 4)),
 ]
+TILING_CASES = [c[:7] + (c[7] + (1,),) for c in TILING_CASES]
+
+
+def _second_set_cases():
+    """One case per kernel of the second instantiation set (two LDS stages; 32-channel chunks with 128 couts), read
+    from the table the kernels are generated from: 2 or 3 input-channel chunks (both parities of the stage ping-pong),
+    ragged image edges, a partly filled last cout tile on every other case."""
+    import json
+    import os
+    from conftest import ROOT
+    with open(os.path.join(ROOT, "yolo_amd", "csrc", "conv_variants.json")) as f:
+        tables = json.load(f)
+    cases = []
+    for key, (k, s) in (("k1b", (1, 1)), ("k3s1b", (3, 1)), ("k3s2b", (3, 2))):
+        for i, (mrep, nrep, ck, f32, nwaves, stages) in enumerate(tables[key]):
+            cin = ck * (3 if i % 2 else 2)
+            cout = 32 * nrep + (40 if i % 2 else 0)
+            H, W = ((37, 29) if i % 2 else (40, 40))
+            cases.append((k, s, cin, cout, H, W, bool(i % 3 == 0), (mrep, nrep, ck, nwaves, stages)))
+    return cases
+
+
+TILING_CASES += _second_set_cases()
 
 
 @pytest.mark.parametrize("k,s,cin,cout,H,W,use_res,tiling", TILING_CASES)

@@ -1,0 +1,146 @@
+"""Library-surface checks on the GPU: explicit and lazy per-device set-up, NMS from two host threads, the NMS paths
+for very many kept rows / very many classes (bit-exact against the C oracle), a whole predict_device step captured
+into a HIP graph and replayed, and argument checks that must fail before any kernel runs."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(rows, counts, want, index=None, want_index=None):
+    counts = counts.cpu().tolist()
+    rows = rows.cpu().numpy()
+    idx = None if index is None else index.cpu().numpy()
+    assert len(counts) == len(want)
+    for b, w in enumerate(want):
+        k = 0 if w is None else w.shape[0]
+        assert counts[b] == k, f"image {b}: kept {counts[b]} vs {k}"
+        if k:
+            assert np.array_equal(rows[b, :k].view(np.uint32), w.view(np.uint32)), f"image {b}: rows differ"
+            if idx is not None:
+                assert np.array_equal(idx[b, :k].astype(np.int64), want_index[b]), f"image {b}: indices differ"
+
+
+def test_init_is_idempotent(gpu_device):
+    from yolo_amd import lib as L
+    torch.cuda.set_device(gpu_device)
+    assert L.LIB.yamd_init() == 0
+    assert L.LIB.yamd_init() == 0
+    assert L.LIB.yamd_version() >= 200
+
+
+def test_nms_from_two_host_threads(gpu_device):
+    """Two host threads, each on its own stream (hence its own workspace), interleave NMS calls on one GPU."""
+    from oracle import postprocess as pp
+    from oracle.gen_golden_synth import synthetic_pred
+    from yolo_amd import torch_utils as tu
+    preds = [synthetic_pred(np.random.RandomState(40 + i), 3, 3000, 20, 640.0, clusters=30) for i in range(2)]
+    wants = [pp.non_max_suppression(p, 640.0, "cxcywh", 0.1, 0.3, return_index=True) for p in preds]
+    errors = []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(gpu_device)
+            stream = torch.cuda.Stream(device=gpu_device)
+            with torch.cuda.stream(stream):
+                dev = torch.from_numpy(preds[i]).to(gpu_device)
+                for _ in range(6):
+                    rows, counts, index = tu.nms_batched(dev, 640.0, "cxcywh", 0.1, 0.3, 0, want_index=True)
+                    stream.synchronize()
+                    _check(rows, counts, wants[i][0], index, wants[i][1])
+        except Exception as e:      # noqa: BLE001  (reported by the main thread)
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_nms_more_than_16384_kept_rows_in_one_image(gpu_device):
+    """Disjoint boxes, all kept: the per-image merge of the kept lists takes its large-image path."""
+    from oracle import postprocess as pp
+    from yolo_amd import torch_utils as tu
+    g = 136                                            # 136 x 136 = 18 496 boxes of 20 x 20 px, 30 px apart
+    ys, xs = np.meshgrid(np.arange(g), np.arange(g), indexing="ij")
+    rng = np.random.RandomState(3)
+    A = g * g
+    box = np.stack((xs.ravel() * 30.0 + 12.0, ys.ravel() * 30.0 + 12.0, np.full(A, 20.0), np.full(A, 20.0)), -1)
+    obj = rng.uniform(0.5, 1.0, (A, 1))
+    cls = rng.uniform(0.3, 1.0, (A, 4))
+    pred = np.concatenate((box, obj, cls), -1).astype(np.float32)[None]
+    want, want_idx = pp.non_max_suppression(pred, 4096.0, "cxcywh", 0.1, 0.3, return_index=True)
+    assert want[0].shape[0] == A > 16384
+    rows, counts, index = tu.nms_batched(torch.from_numpy(pred).to(gpu_device), 4096.0, "cxcywh", 0.1, 0.3, 0,
+                                         want_index=True)
+    _check(rows, counts, want, index, want_idx)
+
+
+def test_nms_300_classes(gpu_device):
+    from oracle import postprocess as pp
+    from oracle.gen_golden_synth import synthetic_pred
+    from yolo_amd import torch_utils as tu
+    pred = synthetic_pred(np.random.RandomState(9), 2, 1500, 300, 640.0, clusters=20)
+    want, want_idx = pp.non_max_suppression(pred, 640.0, "cxcywh", 0.05, 0.3, return_index=True)
+    rows, counts, index = tu.nms_batched(torch.from_numpy(pred).to(gpu_device), 640.0, "cxcywh", 0.05, 0.3, 0,
+                                         want_index=True)
+    _check(rows, counts, want, index, want_idx)
+
+
+def test_rejects_images_that_are_not_rgb(gpu_device):
+    from yolo_amd import lib as L
+    from yolo_amd.param import Yolo5Param
+    from yolo_amd.yolov5 import YoloV5
+    m = YoloV5(Yolo5Param(m_type="s").set_img_size(64))
+    for shape in ((2, 1, 64, 64), (2, 4, 64, 64)):
+        with pytest.raises(L.YamdError):
+            m._forward(torch.zeros(shape, device=gpu_device))
+
+
+def test_predict_device_captured_as_hip_graph(gpu_device):
+    """conv graph -> decode -> NMS recorded into a HIP graph: the step allocates nothing and sets nothing up while it is
+    recorded (persistent arenas, yamd_init), and the launch of the recorded graph equals the eager step bit for bit.
+    Each recorded graph is launched ONCE here: on this ROCm build a second launch of the same executable graph ends in a
+    GPU memory fault although the first is bit-identical to eager and eager steps repeat indefinitely
+    (profiles/r2_hipgraph_second_replay_fault.log), so the test stays on the side that is known to be safe."""
+    from yolo_amd import lib as L, models
+    from yolo_amd.init import seeded_images, seeded_state_dict
+    torch.cuda.set_device(gpu_device)
+    p, m = models.create("v5s", img_size=64)
+    m.load_state_dict(seeded_state_dict(m, seed=5, mode="spread", **models.init_options("v5s")))
+    batches = [torch.from_numpy(seeded_images(4, 64, seed=20 + i)).to(gpu_device) for i in range(3)]
+    eager = []
+    for x in batches:
+        rows, counts = m.predict_device(x)
+        eager.append((rows.clone(), counts.clone()))
+    assert L.LIB.yamd_init() == 0
+    static_in = batches[0].clone()
+    side = torch.cuda.Stream(device=gpu_device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m.predict_device(static_in)              # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    n_allocs = lambda: torch.cuda.memory_stats(gpu_device)["allocation.all.allocated"]      # noqa: E731
+    for x, (rows, counts) in zip(batches, eager):
+        static_in.copy_(x)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            n0 = n_allocs()
+            g_rows, g_counts = m.predict_device(static_in)
+            n1 = n_allocs()
+        assert n1 == n0, "the recorded step allocated device memory"
+        g_counts.fill_(-1)                       # the results must come from the graph launch, not from the warm-up
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g_counts, counts)
+        for b, kb in enumerate(counts.cpu().tolist()):
+            assert torch.equal(g_rows[b, :kb].view(torch.int32), rows[b, :kb].view(torch.int32))
+        del graph
+    assert sum(eager[0][1].cpu().tolist()) > 0

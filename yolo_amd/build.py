@@ -19,16 +19,21 @@ SOURCES = [
     ("yamd_core.hip", []),
     ("yamd_conv.hip", []),
     ("yamd_conv_k1.hip", []),
+    ("yamd_conv_k1b.hip", []),
     ("yamd_conv_k3s1.hip", []),
+    ("yamd_conv_k3s1b.hip", []),
     ("yamd_conv_k3s2.hip", []),
+    ("yamd_conv_k3s2b.hip", []),
     ("yamd_decode.hip", ["-ffp-contract=off"]),
     ("yamd_nms.hip", ["-ffp-contract=off"]),
     ("yamd_preprocess.hip", ["-ffp-contract=off"]),
     ("yamd_metric.hip", ["-ffp-contract=off"]),
     ("yamd_stem.hip", []),
+    ("yamd_microbench.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
 HEADERS = [os.path.join(CSRC, "yamd_common.h"), os.path.join(CSRC, "yamd_conv_kernel.h"),
+           os.path.join(CSRC, "yamd_conv_variants.inc"),
            os.path.join(HERE, "..", "include", "yolo_amd.h")]
 
 

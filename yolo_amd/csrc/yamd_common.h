@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 
+#include <atomic>
+
 #include "../../include/yolo_amd.h"
 
 namespace yamd {
@@ -39,5 +41,31 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Kernels that use more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised, once per
+// (kernel, device).  A DeviceOnce holds one bit per device ordinal.  Every such kernel is also listed in a registry so
+// that yamd_init() can raise them all for the current device up front (nothing is then left to do on the first launch,
+// e.g. under stream capture).  Raising is idempotent, so two host threads racing on the same kernel are harmless.
+struct DeviceOnce {
+    std::atomic<unsigned long long> done{0};
+};
+bool register_kernel(const void *kernel, DeviceOnce *once, int lds_bytes);
+int raise_dynamic_lds(DeviceOnce &once, const void *kernel, int lds_bytes);   // YAMD_OK / YAMD_EHIP, for the current device
+
+// KernelAttr<&kernel, bytes>::ensure(): registers the kernel when the library is loaded and raises its limit on first
+// use on a device
+template <auto KERNEL, int LDS_BYTES>
+struct KernelAttr {
+    static inline DeviceOnce once;
+    static inline const bool registered = register_kernel((const void *)KERNEL, &once, LDS_BYTES);
+    static int ensure()
+    {
+        (void)registered;     // odr-use: the registration runs at load time
+        return raise_dynamic_lds(once, (const void *)KERNEL, LDS_BYTES);
+    }
+};
+
+// per-device set-up of the NMS kernels and their static scratch array (yamd_nms.hip), called by yamd_init
+int nms_init_current_device(int device);
 
 }  // namespace yamd

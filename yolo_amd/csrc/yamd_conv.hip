@@ -4,10 +4,29 @@
 using namespace yamd;
 
 namespace yamd {
-int conv_dispatch_k1(const ConvParams &p, int batch, int tw, int mrep, int nrep, int ck, int f32, int nwaves, hipStream_t st);
-int conv_dispatch_k3s1(const ConvParams &p, int batch, int tw, int mrep, int nrep, int ck, int f32, int nwaves, hipStream_t st);
-int conv_dispatch_k3s2(const ConvParams &p, int batch, int tw, int mrep, int nrep, int ck, int f32, int nwaves, hipStream_t st);
+#define YAMD_DISPATCH_DECL(name) \
+    int name(const ConvParams &p, int batch, int tw, int mrep, int nrep, int ck, int f32, int nwaves, int stages, hipStream_t st)
+YAMD_DISPATCH_DECL(conv_dispatch_k1);
+YAMD_DISPATCH_DECL(conv_dispatch_k1b);
+YAMD_DISPATCH_DECL(conv_dispatch_k3s1);
+YAMD_DISPATCH_DECL(conv_dispatch_k3s1b);
+YAMD_DISPATCH_DECL(conv_dispatch_k3s2);
+YAMD_DISPATCH_DECL(conv_dispatch_k3s2b);
 }  // namespace yamd
+
+namespace {
+// every built kernel: {ksize, stride, mrep, nrep, ck, out_f32, nwaves, stages}
+const int kBuilt[][8] = {
+#include "yamd_conv_variants.inc"
+};
+bool is_built(int ks, int s, int mrep, int nrep, int ck, int f32, int nwaves, int stages)
+{
+    for (const auto &v : kBuilt)
+        if (v[0] == ks && v[1] == s && v[2] == mrep && v[3] == nrep && v[4] == ck && v[5] == f32 && v[6] == nwaves && v[7] == stages)
+            return true;
+    return false;
+}
+}  // namespace
 
 extern "C" int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int cin, int cout, int act, int out_f32)
 {
@@ -27,6 +46,7 @@ extern "C" int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int
     const int groups = (cout + 31) / 32;
     d->mrep = (stride == 2) ? 1 : 2;
     d->nwaves = 4;
+    d->stages = 1;
     d->residual_scale = 1.0f;
     if (out_f32) {
         YAMD_REQUIRE(ksize == 1, "float output is only built for 1x1 convs");
@@ -71,29 +91,21 @@ extern "C" int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int
     return YAMD_OK;
 }
 
-extern "C" int yamd_conv_desc_tune(yamd_conv_desc *d, int mrep, int nrep, int ck, int nwaves)
+extern "C" int yamd_conv_desc_tune(yamd_conv_desc *d, int mrep, int nrep, int ck, int nwaves, int stages)
 {
     YAMD_REQUIRE(d != nullptr, "null descriptor");
     YAMD_REQUIRE(nwaves == 4 || nwaves == 8, "nwaves=%d must be 4 or 8", nwaves);
+    YAMD_REQUIRE(stages == 1 || stages == 2, "stages=%d must be 1 or 2", stages);
     YAMD_REQUIRE((mrep == 1 || mrep == 2) && (nrep == 1 || nrep == 2 || nrep == 4) && (ck == 16 || ck == 32 || ck == 64),
                  "bad tiling mrep=%d nrep=%d ck=%d", mrep, nrep, ck);
     YAMD_REQUIRE(d->cin % ck == 0, "cin=%d is not a multiple of ck=%d", d->cin, ck);
     YAMD_REQUIRE(!d->out_f32, "the float-output kernel has one tiling");
-    bool built;
-    if (d->ksize == 1) {
-        built = ck >= 32 || (ck == 16 && mrep == 2 && (nrep == 1 || nrep == 4) && nwaves == 4);
-        if (nwaves == 8)
-            built = (nrep == 4 && ck == 64) || (mrep == 1 && nrep == 4 && ck == 32) || (nrep == 2 && ck == 64);
-    } else if (d->stride == 1) {
-        built = (ck == 16 && (nrep == 1 || nrep == 4)) || (ck == 32 && (nrep == 1 || nrep == 2));
-    } else {
-        built = (mrep == 1 && ((ck == 16) || (ck == 32 && nrep == 2))) || (mrep == 2 && ck == 16 && nrep >= 2);
-        if (nwaves == 8) built = built && nrep >= 2;
-    }
-    YAMD_REQUIRE(built, "no kernel built for k=%d s=%d mrep=%d nrep=%d ck=%d nwaves=%d", d->ksize, d->stride, mrep, nrep,
-                 ck, nwaves);
+    YAMD_REQUIRE(is_built(d->ksize, d->stride, mrep, nrep, ck, 0, nwaves, stages),
+                 "no kernel built for k=%d s=%d mrep=%d nrep=%d ck=%d nwaves=%d stages=%d", d->ksize, d->stride, mrep, nrep, ck,
+                 nwaves, stages);
     d->mrep = mrep;
     d->nwaves = nwaves;
+    d->stages = stages;
     d->nrep = nrep;
     d->ck = ck;
     const int bn = nrep * 32;
@@ -218,13 +230,24 @@ int conv_impl(const yamd_conv_desc *d, const void *x, int x_cstride, const void 
     p.nchunks = d->cin / d->ck;
     hipStream_t st = (hipStream_t)stream;
 
+    const int stages = d->stages == 2 ? 2 : 1;
+    YAMD_REQUIRE(is_built(KS, S, d->mrep, d->nrep, d->ck, d->out_f32, d->nwaves, stages),
+                 "no conv kernel built for k=%d s=%d mrep=%d nrep=%d ck=%d f32=%d nwaves=%d stages=%d", KS, S, d->mrep, d->nrep,
+                 d->ck, d->out_f32, d->nwaves, stages);
     int rc = 1;
-    if (KS == 1) rc = conv_dispatch_k1(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, d->nwaves, st);
-    else if (S == 1) rc = conv_dispatch_k3s1(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, d->nwaves, st);
-    else rc = conv_dispatch_k3s2(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, d->nwaves, st);
+    if (KS == 1) {
+        rc = conv_dispatch_k1(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, d->nwaves, stages, st);
+        if (rc == 1) rc = conv_dispatch_k1b(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, d->nwaves, stages, st);
+    } else if (S == 1) {
+        rc = conv_dispatch_k3s1(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, d->nwaves, stages, st);
+        if (rc == 1) rc = conv_dispatch_k3s1b(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, d->nwaves, stages, st);
+    } else {
+        rc = conv_dispatch_k3s2(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, d->nwaves, stages, st);
+        if (rc == 1) rc = conv_dispatch_k3s2b(p, batch, TW, d->mrep, d->nrep, d->ck, d->out_f32, d->nwaves, stages, st);
+    }
     if (rc <= 0) return rc;
-    set_error("no conv kernel built for k=%d s=%d mrep=%d nrep=%d ck=%d f32=%d nwaves=%d", KS, S, d->mrep, d->nrep,
-              d->ck, d->out_f32, d->nwaves);
+    set_error("no conv kernel built for k=%d s=%d mrep=%d nrep=%d ck=%d f32=%d nwaves=%d stages=%d", KS, S, d->mrep, d->nrep,
+              d->ck, d->out_f32, d->nwaves, stages);
     return YAMD_EINVAL;
 }
 }  // namespace

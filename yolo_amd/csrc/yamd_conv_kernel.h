@@ -22,7 +22,6 @@
 #include <cstring>
 #include <cstdlib>
 #include <cmath>
-#include <mutex>
 #include <type_traits>
 
 namespace yamd {
@@ -98,8 +97,11 @@ __device__ __forceinline__ void act4(float (&v)[4])
     for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j], ACT);
 }
 
-template <int KS, int S, int TW, int MREP, int NREP, int CK, bool OUT_F32, int ACTK, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_kernel(ConvParams p)
+// STAGES = 1: one LDS image of the current chunk; the next chunk waits in registers and is written between two
+// barriers.  STAGES = 2: two LDS images; the next chunk is written into the other image while the current one is
+// being read, so a chunk costs one barrier and the LDS writes overlap the other waves' MFMAs.
+template <int KS, int S, int TW, int MREP, int NREP, int CK, bool OUT_F32, int ACTK, int NW, int STAGES = 1>
+__global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void conv_igemm_kernel(ConvParams p)
 {
     constexpr int NT = NW * 64;              // threads per workgroup (4 or 8 waves share one weight tile)
     constexpr int PAD = KS / 2;
@@ -112,8 +114,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_kernel(Co
     constexpr int WBYTES = TAPS * KSTEPS * NREP * 1024;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *ldsW = smem;
-    char *ldsA = smem + WBYTES;
 
     // Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  Give every XCD a
     // contiguous range of logical tiles instead, so the cout tiles of one pixel tile (same input) and spatially
@@ -188,7 +188,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_kernel(Co
             ra[u] = ((inb_mask >> u) & 1u) ? v : u32x4{0u, 0u, 0u, 0u};
         });
     };
-    auto write_lds = [&]() __attribute__((always_inline)) {
+    const int stage_bytes = WBYTES + NPH * NPW * RS;          // one LDS image: weights, then the halo tile (multiple of 16)
+    auto write_lds = [&](int stage) __attribute__((always_inline)) {
+        char *ldsW = smem + stage * stage_bytes;
+        char *ldsA = ldsW + WBYTES;
         static_for<WP>([&](auto uc) __attribute__((always_inline)) {
             constexpr int u = decltype(uc)::value;
             const int q = min(tid + u * NT, WBYTES / 16 - 1);
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_kernel(Co
                 for (int j = 0; j < 4; ++j) acc[m][n][4 * i + j] = bv[j];
         }
 
-    write_lds();
+    write_lds(0);
     __syncthreads();
     YAMD_STAMP(2);
     for (int ch = 0; ch < p.nchunks; ++ch) {
@@ -224,6 +227,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_kernel(Co
         if (ch == 1) YAMD_STAMP(5);
 #endif
         if (more) issue_loads(ch + 1);
+        const char *ldsW = smem + (STAGES == 2 ? (ch & 1) * stage_bytes : 0);
+        const char *ldsA = ldsW + WBYTES;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int kh = tap / KS, kw = tap % KS;
@@ -246,10 +251,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_kernel(Co
 #ifdef YAMD_CONV_TRACE
         if (ch == 1) YAMD_STAMP(6);
 #endif
-        __syncthreads();   // every wave is done reading this chunk
-        if (more) {
-            write_lds();
+        if constexpr (STAGES == 2) {
+            // the other image was last read one iteration ago, and every wave has passed that iteration's barrier
+            if (more) write_lds((ch + 1) & 1);
             __syncthreads();
+        } else {
+            __syncthreads();   // every wave is done reading this chunk
+            if (more) {
+                write_lds(0);
+                __syncthreads();
+            }
         }
 #ifdef YAMD_CONV_TRACE
         if (ch == 1) YAMD_STAMP(7);
@@ -429,24 +440,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_igemm_kernel(Co
     YAMD_STAMP(4);
 }
 
-template <int KS, int S, int TW, int MREP, int NREP, int CK, bool OUT_F32, int ACTK, int NW = 4>
+template <int KS, int S, int TW, int MREP, int NREP, int CK, bool OUT_F32, int ACTK, int NW = 4, int STAGES = 1>
 int launch_conv(const ConvParams &p, int batch, hipStream_t stream)
 {
     constexpr int NPW = (TW - 1) * S + KS;
     constexpr int RS = CK * 2 + 16;
     constexpr int WBYTES = KS * KS * (CK / 16) * NREP * 1024;
     const int NPH = (p.TH - 1) * S + KS;
-    size_t lds = (size_t)WBYTES + (size_t)NPH * NPW * RS;
+    size_t lds = ((size_t)WBYTES + (size_t)NPH * NPW * RS) * STAGES;
     const size_t epi = (size_t)NW * 32 * (OUT_F32 ? NREP * 128 + 16 : NREP * 64 + 16);   // epilogue staging tiles
     if (lds < epi) lds = epi;
     YAMD_REQUIRE(lds <= 160 * 1024, "conv tile needs %zu bytes of LDS", lds);
-    auto kern = conv_igemm_kernel<KS, S, TW, MREP, NREP, CK, OUT_F32, ACTK, NW>;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [&] {
-        attr_err = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    YAMD_HIP(attr_err);
+    auto kern = conv_igemm_kernel<KS, S, TW, MREP, NREP, CK, OUT_F32, ACTK, NW, STAGES>;
+    {
+        const int rc = KernelAttr<&conv_igemm_kernel<KS, S, TW, MREP, NREP, CK, OUT_F32, ACTK, NW, STAGES>, 160 * 1024>::ensure();
+        if (rc != YAMD_OK) return rc;
+    }
     const long long total = (long long)batch * p.tiles_y * p.tiles_x * p.n_tiles;
     YAMD_REQUIRE(total > 0 && total < (1ll << 31) - 8, "conv grid out of range");
     ConvParams q = p;
@@ -458,18 +467,18 @@ int launch_conv(const ConvParams &p, int batch, hipStream_t stream)
 }
 
 // one tiling, both tile widths, SiLU-specialised or run-time activation
-template <int KS, int S, int MREP, int NREP, int CK, bool OUT_F32, int NW = 4>
+template <int KS, int S, int MREP, int NREP, int CK, bool OUT_F32, int NW = 4, int STAGES = 1>
 int launch_conv_variant(const ConvParams &p, int batch, int tw, hipStream_t st)
 {
     if constexpr (OUT_F32) {
-        return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, true, -1, NW>(p, batch, st)
-                        : launch_conv<KS, S, 20, MREP, NREP, CK, true, -1, NW>(p, batch, st);
+        return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, true, -1, NW, STAGES>(p, batch, st)
+                        : launch_conv<KS, S, 20, MREP, NREP, CK, true, -1, NW, STAGES>(p, batch, st);
     } else {
         if (p.act == YAMD_ACT_SILU)
-            return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, false, YAMD_ACT_SILU, NW>(p, batch, st)
-                            : launch_conv<KS, S, 20, MREP, NREP, CK, false, YAMD_ACT_SILU, NW>(p, batch, st);
-        return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, false, -1, NW>(p, batch, st)
-                        : launch_conv<KS, S, 20, MREP, NREP, CK, false, -1, NW>(p, batch, st);
+            return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, false, YAMD_ACT_SILU, NW, STAGES>(p, batch, st)
+                            : launch_conv<KS, S, 20, MREP, NREP, CK, false, YAMD_ACT_SILU, NW, STAGES>(p, batch, st);
+        return tw == 16 ? launch_conv<KS, S, 16, MREP, NREP, CK, false, -1, NW, STAGES>(p, batch, st)
+                        : launch_conv<KS, S, 20, MREP, NREP, CK, false, -1, NW, STAGES>(p, batch, st);
     }
 }
 

@@ -2,6 +2,8 @@
 #include "yamd_common.h"
 
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace yamd {
 static thread_local char g_err[512] = "";
@@ -12,12 +14,65 @@ void set_error(const char *fmt, ...)
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+namespace {
+struct KernelEntry {
+    const void *kernel;
+    DeviceOnce *once;
+    int lds_bytes;
+};
+std::mutex &registry_mutex()
+{
+    static std::mutex m;
+    return m;
+}
+std::vector<KernelEntry> &registry()
+{
+    static std::vector<KernelEntry> r;     // function-local: usable from other files' static initialisers
+    return r;
+}
+}  // namespace
+
+bool register_kernel(const void *kernel, DeviceOnce *once, int lds_bytes)
+{
+    std::lock_guard<std::mutex> g(registry_mutex());
+    registry().push_back({kernel, once, lds_bytes});
+    return true;
+}
+
+int raise_dynamic_lds(DeviceOnce &once, const void *kernel, int lds_bytes)
+{
+    int dev = 0;
+    YAMD_HIP(hipGetDevice(&dev));
+    YAMD_REQUIRE(dev >= 0 && dev < 64, "device ordinal %d outside [0, 64)", dev);
+    const unsigned long long bit = 1ull << dev;
+    if (once.done.load(std::memory_order_acquire) & bit) return YAMD_OK;
+    YAMD_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    once.done.fetch_or(bit, std::memory_order_release);
+    return YAMD_OK;
+}
 }  // namespace yamd
 
 using namespace yamd;
 
 extern "C" const char *yamd_last_error(void) { return g_err; }
-extern "C" int yamd_version(void) { return 100; }
+extern "C" int yamd_version(void) { return 200; }
+
+extern "C" int yamd_init(void)
+{
+    int dev = 0;
+    YAMD_HIP(hipGetDevice(&dev));
+    std::vector<KernelEntry> entries;
+    {
+        std::lock_guard<std::mutex> g(registry_mutex());
+        entries = registry();
+    }
+    for (const KernelEntry &e : entries) {
+        const int rc = raise_dynamic_lds(*e.once, e.kernel, e.lds_bytes);
+        if (rc != YAMD_OK) return rc;
+    }
+    return nms_init_current_device(dev);
+}
 
 namespace {
 
@@ -286,12 +341,18 @@ int maxpool_cascade(int radius, const void *x, int x_cstride, void *y1, void *y2
                     int c, void *stream)
 {
     YAMD_REQUIRE(x && y1 && y2 && y3, "null argument");
-    YAMD_REQUIRE(batch > 0 && h > 0 && w > 0 && h * w <= 1024 && c > 0 && c % 8 == 0, "maxpool: bad shape %dx%dx%d", h, w, c);
+    YAMD_REQUIRE(batch > 0 && h > 0 && w > 0 && h * w <= 4096 && c > 0 && c % 8 == 0,
+                 "maxpool cascade: bad shape %dx%dx%d (planes up to 4096 pixels, c %% 8 == 0)", h, w, c);
     YAMD_REQUIRE(x_cstride % 8 == 0 && y_cstride % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y1 % 16) == 0 &&
                      ((uintptr_t)y2 % 16) == 0 && ((uintptr_t)y3 % 16) == 0,
                  "maxpool needs 16-byte aligned pixels");
     const size_t lds = (size_t)h * w * 16 * 2;
     auto kern = radius == 2 ? maxpool_cascade_kernel<2> : maxpool_cascade_kernel<1>;
+    {
+        const int rc = radius == 2 ? KernelAttr<&maxpool_cascade_kernel<2>, 128 * 1024>::ensure()
+                                   : KernelAttr<&maxpool_cascade_kernel<1>, 128 * 1024>::ensure();
+        if (rc != YAMD_OK) return rc;
+    }
     hipLaunchKernelGGL(kern, dim3(batch * (c / 8)), dim3(256), lds, (hipStream_t)stream, (const __bf16 *)x, x_cstride,
                        (__bf16 *)y1, (__bf16 *)y2, (__bf16 *)y3, y_cstride, h, w, c / 8);
     YAMD_LAUNCH_CHECK();

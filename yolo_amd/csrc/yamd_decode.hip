@@ -262,9 +262,10 @@ extern "C" int yamd_decode_anchor(int kind, const float *raw, int batch, int h, 
     YAMD_REQUIRE(c >= need && point_num >= 0, "c=%d too small for kind %d with %d points", c, kind, point_num);
     const size_t lds = (size_t)PIX * (na * c + 2) * sizeof(float);
     YAMD_REQUIRE(lds <= 160 * 1024 && (long long)PIX * c * c < (1ll << 22), "na*c=%d too large for the decode tile", na * c);
-    static hipError_t attr_err = hipFuncSetAttribute((const void *)decode_anchor_kernel,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    YAMD_HIP(attr_err);
+    {
+        const int rc = KernelAttr<&decode_anchor_kernel, 160 * 1024>::ensure();
+        if (rc != YAMD_OK) return rc;
+    }
     AnchorDecodeParams p;
     p.raw = raw;
     p.out = out;

@@ -27,7 +27,7 @@
 #include "yamd_common.h"
 
 #include <cmath>
-#include <cstdlib>
+#include <atomic>
 
 using namespace yamd;
 
@@ -43,7 +43,8 @@ struct NmsParams {
     u64 *tmp_key, *tmp_meta, *bkey, *skey, *kseg;
     float4 *sbox, *mbox;
     u32 *mrank, *posr;
-    int sort_cap, dbg;
+    int sort_cap;
+    int frows;                   // rows per workgroup of the filter (256, fewer when a row is very wide)
     u32 *img_count, *cls_count, *cls_off, *kcnt;
     float *out_rows;
     int *out_index, *out_counts;
@@ -88,12 +89,12 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(NmsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float srow[];
     const int RSTR = p.C | 1;
-    u32 *hist = (u32 *)(srow + FROWS * RSTR);   // nc
+    u32 *hist = (u32 *)(srow + p.frows * RSTR); // nc
     u32 *cbase = hist + p.nc;                   // nc
     u32 *misc = cbase + p.nc;                   // [0] block total, [1] image base
     const int tid = threadIdx.x;
-    const int r0 = blockIdx.x * FROWS;
-    const int nrows = min(FROWS, p.A - r0);
+    const int r0 = blockIdx.x * p.frows;
+    const int nrows = min(p.frows, p.A - r0);
     const long long b = blockIdx.y;
     for (int c = tid; c < p.nc; c += 256) hist[c] = 0;
     if (tid == 0) misc[0] = 0;
@@ -137,6 +138,13 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(NmsParams p)
         p.tmp_key[pos] = key;
         p.tmp_meta[pos] = ((u64)cls << 32) | (u64)(cbase[cls] + lt);
     }
+}
+
+// zeroes the per-image / per-class counters at the start of the workspace (16-byte pieces)
+__global__ __launch_bounds__(256) void nms_clear_kernel(uint4 *counters, int pieces)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < pieces) counters[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 __global__ void nms_scan_kernel(NmsParams p)
@@ -468,7 +476,6 @@ __global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
         }
     }
     __syncthreads();
-    if (p.dbg & 1) { if (tid == 0) p.kcnt[b * p.nc + cls] = 0; return; }
 
     // ---- sweep state in LDS (aliases the sort array)
     const u32 ng = (n + 63) / 64;                       // groups == tiles == mask words
@@ -586,7 +593,7 @@ __global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
                 if (wave == 0) { nsp = posr[j]; nkey = skey[j]; }
             }
         }
-        if (nk > 0 && have_next && !(p.dbg & 2)) {
+        if (nk > 0 && have_next) {
             const u32 first_later = (t + 1) * 64;
             float4 kx = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((u32)lane < nk) kx = kb[lane];
@@ -905,15 +912,43 @@ extern "C" size_t yamd_nms_workspace_bytes(int batch, int a, int c, int n_extra)
     return ws_layout(batch, a, nc).total;
 }
 
+namespace {
+int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, int n_extra, float img_size, float conf_thr,
+                     double iou_thr, float *out_rows, int *out_index, int max_out, int *out_counts, void *workspace,
+                     size_t workspace_bytes, void *stream);
+}  // namespace
+
+namespace yamd {
+int nms_init_current_device(int device)
+{
+    (void)device;
+    int rc = KernelAttr<&nms_filter_kernel, 160 * 1024>::ensure();
+    if (rc == YAMD_OK) rc = KernelAttr<&nms_segment_kernel, 160 * 1024>::ensure();
+    if (rc == YAMD_OK) rc = KernelAttr<&nms_gather_sort_kernel, 150 * 1024>::ensure();
+    return rc;
+}
+}  // namespace yamd
+
 extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int in_cxcywh, int n_extra, float img_size,
                                 float conf_thr, double iou_thr, float *out_rows, int *out_index, int max_out,
                                 int *out_counts, void *workspace, size_t workspace_bytes, void *stream)
+{
+    YAMD_REQUIRE(workspace, "null argument");
+    return nms_batched_impl(pred, batch, a, c, in_cxcywh, n_extra, img_size, conf_thr, iou_thr, out_rows, out_index, max_out,
+                            out_counts, workspace, workspace_bytes, stream);
+}
+
+namespace {
+int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, int n_extra, float img_size, float conf_thr,
+                     double iou_thr, float *out_rows, int *out_index, int max_out, int *out_counts, void *workspace,
+                     size_t workspace_bytes, void *stream)
 {
     YAMD_REQUIRE(pred && out_rows && out_counts && workspace, "null argument");
     const int nc = c - 5 - n_extra;
     YAMD_REQUIRE(batch > 0 && a > 0 && n_extra >= 0 && nc > 0 && nc <= 65535 && batch <= 65535, "bad shape B=%d A=%d C=%d extra=%d", batch, a,
                  c, n_extra);
     YAMD_REQUIRE(max_out > 0, "max_out must be positive");
+    YAMD_REQUIRE((long long)batch * nc <= (1ll << 26), "batch x classes = %lld exceeds 2^26", (long long)batch * nc);
     // classes are swept independently; that equals the reference only while offset boxes of different
     // classes cannot intersect and IoU 0 never suppresses
     YAMD_REQUIRE(img_size - 1.0f < 4096.0f && img_size >= 1.0f, "img_size=%g outside (1, 4096]", (double)img_size);
@@ -924,7 +959,10 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
         set_error("workspace too small: %zu < %zu", workspace_bytes, L.total);
         return YAMD_ENOSPC;
     }
-    const size_t flds = (size_t)FROWS * (c | 1) * 4 + (size_t)nc * 8 + 16;
+    // the filter stages FROWS rows per workgroup in LDS, fewer when a row is so wide that they would not fit
+    int frows = FROWS;
+    while (frows > 8 && (size_t)frows * (c | 1) * 4 + (size_t)nc * 8 + 16 > 150 * 1024) frows >>= 1;
+    const size_t flds = (size_t)frows * (c | 1) * 4 + (size_t)nc * 8 + 16;
     YAMD_REQUIRE(flds <= 150 * 1024, "C=%d too wide for the filter tile", c);
     YAMD_REQUIRE(a <= 65536, "A=%d exceeds the 65536 anchors per image supported", a);
     int sort_cap = 8;
@@ -941,7 +979,6 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     p.B = batch; p.A = a; p.C = c; p.in_cxcywh = in_cxcywh ? 1 : 0; p.n_extra = n_extra; p.nc = nc;
     p.W = 7 + n_extra;
     p.sort_cap = sort_cap;
-    { const char *e = getenv("YAMD_NMS_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.max_out = max_out;
     p.hi = img_size - 1.0f;
     p.conf_thr = conf_thr;
@@ -968,16 +1005,21 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     p.out_counts = out_counts;
     hipStream_t st = (hipStream_t)stream;
 
-    static bool attr_done = false;
-    if (!attr_done) {
-        YAMD_HIP(hipFuncSetAttribute((const void *)nms_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        YAMD_HIP(hipFuncSetAttribute((const void *)nms_segment_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        YAMD_HIP(hipFuncSetAttribute((const void *)nms_gather_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_done = true;
+    {
+        int rc = KernelAttr<&nms_filter_kernel, 160 * 1024>::ensure();
+        if (rc == YAMD_OK) rc = KernelAttr<&nms_segment_kernel, 160 * 1024>::ensure();
+        if (rc == YAMD_OK) rc = KernelAttr<&nms_gather_sort_kernel, 150 * 1024>::ensure();
+        if (rc != YAMD_OK) return rc;
     }
-    YAMD_HIP(hipMemsetAsync(ws + L.counters, 0, L.counters_bytes, st));
-    const int achunks = ceil_div(a, FROWS);
-    hipLaunchKernelGGL(nms_filter_kernel, dim3(achunks, batch), dim3(256), flds, st, p);
+    // the counters are cleared by a kernel, not a memset, so that a captured step consists of kernel nodes only
+    {
+        const int pieces = (int)(L.counters_bytes / 16);
+        hipLaunchKernelGGL(nms_clear_kernel, dim3(ceil_div(pieces, 256)), dim3(256), 0, st, (uint4 *)(ws + L.counters), pieces);
+        YAMD_LAUNCH_CHECK();
+    }
+    const int achunks = ceil_div(a, 256);
+    p.frows = frows;
+    hipLaunchKernelGGL(nms_filter_kernel, dim3(ceil_div(a, frows), batch), dim3(256), flds, st, p);
     YAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(64), 0, st, p);
     YAMD_LAUNCH_CHECK();
@@ -996,6 +1038,7 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
 }
+}  // namespace
 
 extern "C" int yamd_compact_rows(const float *rows, const int *counts, int batch, int max_out, int width, float *compact,
                                  long long *offsets, void *stream)

@@ -47,12 +47,16 @@ class ConvLayer:
         self.pack(tiling)
 
     def pack(self, tiling: Optional[Tuple[int, ...]] = None) -> None:
-        """(Re)build the descriptor and the packed weights; ``tiling`` = (mrep, nrep, ck) overrides the default."""
+        """(Re)build the descriptor and the packed weights; ``tiling`` = (mrep, nrep, ck, nwaves[, stages]) overrides
+        the default."""
         name = self.name
         self.desc = _lib.ConvDesc()
         _lib.check(LIB.yamd_conv_desc_init(ctypes.byref(self.desc), *self._args), f"conv_desc_init[{name}]")
         if tiling is not None:
-            _lib.check(LIB.yamd_conv_desc_tune(ctypes.byref(self.desc), *tiling), f"conv_desc_tune[{name}]")
+            t = tuple(int(v) for v in tiling)
+            t = t + (4,) * (4 - len(t)) if len(t) < 4 else t           # older tables: no nwaves / stages column
+            t = t + (1,) if len(t) == 4 else t
+            _lib.check(LIB.yamd_conv_desc_tune(ctypes.byref(self.desc), *t), f"conv_desc_tune[{name}]")
         self.desc.residual_scale = self.residual_scale
         wp = torch.empty(self.desc.packed_w_elems, dtype=torch.int16)
         bp = torch.empty(self.desc.cout_pad, dtype=torch.float32)
@@ -64,8 +68,8 @@ class ConvLayer:
         self.b_dev: Optional[torch.Tensor] = None
 
     @property
-    def tiling(self) -> Tuple[int, int, int, int]:
-        return (self.desc.mrep, self.desc.nrep, self.desc.ck, self.desc.nwaves)
+    def tiling(self) -> Tuple[int, int, int, int, int]:
+        return (self.desc.mrep, self.desc.nrep, self.desc.ck, self.desc.nwaves, self.desc.stages)
 
     def to(self, device) -> None:
         if self.w_dev is None or self.w_dev.device != torch.device(device):
@@ -112,6 +116,7 @@ class Program:
         self.alias: Dict[str, Tuple[str, int]] = {}     # buffer -> (wider buffer it lives in, first channel)
         self._alloc: Dict[Tuple[int, str], Dict[str, torch.Tensor]] = {}
         self._n = 0
+        self.span_sink: Optional[list] = None    # when set, every run() appends its conv spans here (see run)
 
     # ---- recording -------------------------------------------------------------------------------
     def buffer(self, h: int, w: int, c: int, dtype=torch.bfloat16, name: Optional[str] = None) -> View:
@@ -359,6 +364,9 @@ class Program:
         return best
 
     # ---- accounting ------------------------------------------------------------------------------
+    def n_conv_launches(self) -> int:
+        return sum(1 for op in self.ops if op[0] in ("conv", "stem"))
+
     def conv_macs_per_image(self) -> int:
         total = 0
         for op in self.ops:
@@ -422,20 +430,39 @@ class Program:
         t = bufs[buf]
         return t.data_ptr() + coff * t.element_size(), t.shape[-1]
 
-    def run(self, images: torch.Tensor, timings: Optional[list] = None) -> Dict[str, torch.Tensor]:
+    def run(self, images: torch.Tensor, timings: Optional[list] = None, conv_spans: Optional[list] = None
+            ) -> Dict[str, torch.Tensor]:
         """images: (B,3,H,W) float32 NCHW on the GPU.  Returns {output name: tensor view}; raw head
         outputs are float32 NHWC ``(B,h,w,c)``.  Work is enqueued on torch's current stream.
         If ``timings`` is a list, every op is bracketed by events on that stream and
-        ``(kind, name, start_event, end_event, flops, bytes)`` tuples are appended (profiling aid)."""
+        ``(kind, name, start_event, end_event, flops, bytes)`` tuples are appended (profiling aid).
+        If ``conv_spans`` is a list, every maximal run of consecutive conv launches is bracketed by one event pair on
+        that stream and ``(start_event, end_event)`` is appended: the conv kernels' time inside a running pipeline
+        at the cost of a dozen event records per step."""
         _lib.require_gpu(images, torch.float32, "images")
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise _lib.YamdError(f"images must be (batch, 3, H, W), got {tuple(images.shape)}")
         B, cin, H, W = images.shape
         if (H, W) != (self.img_h, self.img_w):
             raise _lib.YamdError(f"program was built for {self.img_h}x{self.img_w} images, got {H}x{W}")
         bufs = self._buffers_for(B, images.device)
         st = _lib.current_stream()
         P = self._ptr
+        span_open = None
+        if conv_spans is None:
+            conv_spans = self.span_sink
         for op in self.ops:
             kind = op[0]
+            if conv_spans is not None:
+                is_conv = kind in ("conv", "stem")
+                if is_conv and span_open is None:
+                    span_open = torch.cuda.Event(enable_timing=True)
+                    span_open.record()
+                elif not is_conv and span_open is not None:
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    conv_spans.append((span_open, ev))
+                    span_open = None
             if timings is not None:
                 ev0 = torch.cuda.Event(enable_timing=True)
                 ev0.record()
@@ -501,6 +528,10 @@ class Program:
                     timings.append(("conv", op[1].name, ev0, ev1) + self.op_cost(op, B))
                 else:
                     timings.append((kind, op[1].name if kind == "conv" else kind, ev0, ev1) + self.op_cost(op, B))
+        if span_open is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            conv_spans.append((span_open, ev))
         res = {}
         for name, v in self.outputs.items():
             buf, coff = self.resolve(v)

@@ -63,6 +63,7 @@ class TaskModel(nn.Module):
         super().__init__()
         self._program: Optional[Program] = None
         self._program_key = None
+        self._arena = torch_utils.Arena()      # decode / NMS buffers of predict_device, re-used from call to call
 
     def invalidate(self) -> None:
         """Drop the compiled plan (call after changing weights in place)."""
@@ -72,8 +73,18 @@ class TaskModel(nn.Module):
         self.invalidate()
         return super().load_state_dict(*a, **k)
 
+    def _plan_key(self):
+        """Everything the compiled plan depends on: the identity and version counter of every parameter and buffer
+        (an in-place update, ``load_state_dict`` on the model or on any submodule, ``.data`` assignment and ``fuse()``
+        all change one of the two) and the Param fields ``_compile`` and the decode read."""
+        p = self.param
+        weights = tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        cfg = (p.img_size, getattr(p, "class_num", None), repr(getattr(p, "anchors", None)),
+               tuple(getattr(p, "strides", ())), getattr(p, "m_type", None))
+        return cfg, weights
+
     def program(self) -> Program:
-        key = (self.param.img_size,)
+        key = self._plan_key()
         if self._program is None or self._program_key != key:
             if self.param.img_size % max(self.param.strides):
                 raise _lib.YamdError(f"img_size must be a multiple of {max(self.param.strides)}")
@@ -97,15 +108,21 @@ class TaskModel(nn.Module):
     def raw_heads(self, images: torch.Tensor) -> List[torch.Tensor]:      # pragma: no cover - abstract
         raise NotImplementedError
 
-    def decode_predict(self, raws) -> torch.Tensor:                       # pragma: no cover - abstract
+    def decode_predict(self, raws, arena=None) -> torch.Tensor:           # pragma: no cover - abstract
         raise NotImplementedError
 
-    def nms_predict(self, pred: torch.Tensor):                            # pragma: no cover - abstract
+    def nms_predict(self, pred: torch.Tensor, arena=None):                # pragma: no cover - abstract
         raise NotImplementedError
 
     def predict_device(self, images: torch.Tensor):
-        """Whole path on the device: returns (rows (B,A,W), counts (B,)) without synchronising."""
-        return self.nms_predict(self.decode_predict(self.raw_heads(images)))
+        """Whole path on the device: returns (rows (B,A,W), counts (B,)) without synchronising.
+
+        Activations, the decoded tensor, the NMS scratch and both results live in buffers that persist between
+        calls (``Program`` arena + ``self._arena``): a call with the same batch size allocates nothing and writes
+        to the same addresses as the one before, so the results are valid until the next call on this model, and
+        the call can be recorded into a HIP graph (after one eager call, which sizes the buffers and sets up the
+        kernels) and replayed."""
+        return self.nms_predict(self.decode_predict(self.raw_heads(images), self._arena), self._arena)
 
     def fuse(self):
         """Models without a re-parameterisation step in the reference raise there too (model/Layer.py TaskLayer.fuse);
@@ -136,9 +153,9 @@ class AnchorTaskModel(TaskModel):
         na = self.param.anchor_num
         return self.param.anchors[level * na:(level + 1) * na]
 
-    def _merge(self, raws, clamp_points: bool) -> torch.Tensor:
+    def _merge(self, raws, clamp_points: bool, arena=None) -> torch.Tensor:
         return torch_utils.decode_anchor_levels(raws, self.param.anchors, self.param.strides, self.param.img_size,
-                                                self.DECODE_KIND, self.POINT_NUM, clamp_points)
+                                                self.DECODE_KIND, self.POINT_NUM, clamp_points, arena=arena)
 
     def _forward(self, images: torch.Tensor) -> List[torch.Tensor]:
         """[(B, A, C)] merged over levels, cxcywh in input pixels."""
@@ -161,13 +178,13 @@ class AnchorTaskModel(TaskModel):
     def _n_extra(self) -> int:
         return (3 if self.POINT_CONF else 2) * self.POINT_NUM
 
-    def decode_predict(self, raws) -> torch.Tensor:
+    def decode_predict(self, raws, arena=None) -> torch.Tensor:
         clamp = self.POINT_CONF if self.CLAMP_POINTS_IN_PREDICT is None else self.CLAMP_POINTS_IN_PREDICT
-        return self._merge(raws, self.POINT_NUM > 0 and clamp)
+        return self._merge(raws, self.POINT_NUM > 0 and clamp, arena)
 
-    def nms_predict(self, pred: torch.Tensor):
+    def nms_predict(self, pred: torch.Tensor, arena=None):
         rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "cxcywh", self.param.conf_threshold,
-                                                  self.param.nms_threshold, self._n_extra())
+                                                  self.param.nms_threshold, self._n_extra(), arena=arena)
         return rows, counts
 
     def predict(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:

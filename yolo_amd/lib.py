@@ -17,10 +17,11 @@ DECODE_V5, DECODE_V3, DECODE_POSE, DECODE_FACE = 0, 1, 2, 3
 
 # every symbol include/yolo_amd.h declares
 EXPORTS = [
-    "yamd_last_error", "yamd_version", "yamd_conv_desc_init", "yamd_conv_desc_tune", "yamd_conv_pack_weights", "yamd_conv2d_bias_act", "yamd_conv2d_bias_act_split",
+    "yamd_last_error", "yamd_version", "yamd_init", "yamd_conv_desc_init", "yamd_conv_desc_tune", "yamd_conv_pack_weights", "yamd_conv2d_bias_act", "yamd_conv2d_bias_act_split",
     "yamd_focus_pack", "yamd_nchw_to_nhwc16", "yamd_upsample2x", "yamd_maxpool2", "yamd_maxpool5_cascade", "yamd_maxpool3_cascade",
     "yamd_copy_channels", "yamd_depth_to_space2", "yamd_decode_ltrb_points",
     "yamd_decode_anchor", "yamd_decode_dfl", "yamd_decode_dfl_unit_conf", "yamd_decode_dfl_points", "yamd_nms_workspace_bytes", "yamd_nms_batched", "yamd_compact_rows", "yamd_letterbox_workspace_bytes", "yamd_letterbox_u8", "yamd_detect_match", "yamd_stem_packed_elems", "yamd_stem_pack_weights", "yamd_stem_conv",
+    "yamd_microbench_mfma_bf16", "yamd_microbench_copy",
 ]
 
 
@@ -28,7 +29,7 @@ class ConvDesc(ctypes.Structure):
     """Mirror of ``yamd_conv_desc``."""
     _fields_ = [("ksize", c_int32), ("stride", c_int32), ("cin", c_int32), ("cout", c_int32), ("act", c_int32),
                 ("out_f32", c_int32), ("nrep", c_int32), ("ck", c_int32), ("mrep", c_int32), ("cout_pad", c_int32),
-                ("packed_w_elems", c_int64), ("nwaves", c_int32), ("residual_scale", ctypes.c_float)]
+                ("packed_w_elems", c_int64), ("nwaves", c_int32), ("residual_scale", ctypes.c_float), ("stages", c_int32)]
 
 
 class YamdError(RuntimeError):
@@ -48,8 +49,9 @@ def _load() -> ctypes.CDLL:
     lib.yamd_last_error.restype = ctypes.c_char_p
     lib.yamd_last_error.argtypes = []
     lib.yamd_version.restype = c_int
+    lib.yamd_init.argtypes = []
     lib.yamd_conv_desc_init.argtypes = [P(ConvDesc), c_int, c_int, c_int, c_int, c_int, c_int]
-    lib.yamd_conv_desc_tune.argtypes = [P(ConvDesc), c_int, c_int, c_int, c_int]
+    lib.yamd_conv_desc_tune.argtypes = [P(ConvDesc), c_int, c_int, c_int, c_int, c_int]
     lib.yamd_conv_pack_weights.argtypes = [P(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p]
     lib.yamd_conv2d_bias_act.argtypes = [P(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                          c_int, c_int, c_int, c_int, c_void_p]
@@ -79,6 +81,8 @@ def _load() -> ctypes.CDLL:
     lib.yamd_stem_packed_elems.argtypes = [c_int, c_int]
     lib.yamd_stem_pack_weights.argtypes = [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.yamd_stem_conv.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]
+    lib.yamd_microbench_mfma_bf16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
+    lib.yamd_microbench_copy.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
     lib.yamd_letterbox_workspace_bytes.restype = c_size_t
     lib.yamd_letterbox_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.yamd_letterbox_u8.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

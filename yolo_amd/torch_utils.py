@@ -6,6 +6,7 @@ the HIP kernels behind ``yamd_nms_batched`` -- no per-image Python loop, one dev
 the counts.  ``fuse_conv_and_bn`` is the host-side BatchNorm folding used when a plan is compiled.
 """
 import ctypes
+import threading
 from typing import List, Optional, Tuple, Union
 
 import numpy as np
@@ -17,21 +18,51 @@ from . import lib as _lib
 LIB = _lib.LIB
 
 _ws_cache = {}
+_ws_lock = threading.Lock()
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    key = str(device)
-    ws = _ws_cache.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _ws_cache[key] = ws
+    """NMS scratch, one per (device, stream): calls on different streams (or from different host threads, each on
+    its own stream) never share a workspace; calls on one stream are ordered, so they can."""
+    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
+    with _ws_lock:
+        ws = _ws_cache.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            _ws_cache[key] = ws
     return ws
+
+
+class Arena:
+    """Named device buffers that persist between calls, so that a step re-uses the same addresses every time
+    (no allocator traffic per batch, and a step recorded into a HIP graph replays onto memory it still owns).
+    A buffer is re-allocated only when its shape, dtype or device changes."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, name: str, shape, dtype, device) -> torch.Tensor:
+        t = self._bufs.get(name)
+        shape = tuple(int(v) for v in shape)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype or t.device != torch.device(device):
+            t = torch.empty(shape, dtype=dtype, device=device)
+            self._bufs[name] = t
+        return t
+
+    def clear(self) -> None:
+        self._bufs.clear()
+
+
+def _out(arena: Optional[Arena], name: str, shape, dtype, device) -> torch.Tensor:
+    return torch.empty(shape, dtype=dtype, device=device) if arena is None else arena.get(name, shape, dtype, device)
 
 
 def nms_batched(prediction: torch.Tensor, img_size: float, in_fmt: str, conf_threshold: float,
                 nms_threshold: float, n_extra: int = 0, max_out: Optional[int] = None,
-                want_index: bool = False) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
-    """Device-side result: rows (B, max_out, 7+n_extra) float32, counts (B,) int32, index (B, max_out) int32."""
+                want_index: bool = False, arena: Optional[Arena] = None
+                ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    """Device-side result: rows (B, max_out, 7+n_extra) float32, counts (B,) int32, index (B, max_out) int32.
+    With an ``arena`` the outputs and the scratch live in its persistent buffers (overwritten by the next call)."""
     _lib.require_gpu(prediction, torch.float32, "prediction")
     if prediction.dim() != 3:
         raise _lib.YamdError("prediction must be (batch, anchors, columns)")
@@ -40,13 +71,13 @@ def nms_batched(prediction: torch.Tensor, img_size: float, in_fmt: str, conf_thr
     B, A, C = prediction.shape
     max_out = A if max_out is None else int(max_out)
     dev = prediction.device
-    rows = torch.empty((B, max_out, 7 + n_extra), dtype=torch.float32, device=dev)
-    counts = torch.empty((B,), dtype=torch.int32, device=dev)
-    index = torch.empty((B, max_out), dtype=torch.int32, device=dev) if want_index else None
+    rows = _out(arena, "nms_rows", (B, max_out, 7 + n_extra), torch.float32, dev)
+    counts = _out(arena, "nms_counts", (B,), torch.int32, dev)
+    index = _out(arena, "nms_index", (B, max_out), torch.int32, dev) if want_index else None
     nbytes = LIB.yamd_nms_workspace_bytes(B, A, C, n_extra)
     if nbytes == 0:
         raise _lib.YamdError(f"bad NMS shape B={B} A={A} C={C} extra={n_extra}")
-    ws = _workspace(nbytes, dev)
+    ws = _workspace(nbytes, dev) if arena is None else arena.get("nms_workspace", (nbytes,), torch.uint8, dev)
     # the comparison 'score >= conf_threshold' is done in float32, as torch does for a python scalar
     conf32 = float(torch.tensor(conf_threshold, dtype=torch.float32))
     _lib.check(LIB.yamd_nms_batched(prediction.data_ptr(), B, A, C, 1 if in_fmt == "cxcywh" else 0, n_extra,
@@ -56,12 +87,13 @@ def nms_batched(prediction: torch.Tensor, img_size: float, in_fmt: str, conf_thr
     return rows, counts, index
 
 
-def rows_to_host(rows: torch.Tensor, counts: torch.Tensor) -> List[Optional["np.ndarray"]]:
+def rows_to_host(rows: torch.Tensor, counts: torch.Tensor, arena: Optional[Arena] = None
+                 ) -> List[Optional["np.ndarray"]]:
     """Kept rows of the whole batch -> the reference's per-image list of ndarrays (None when empty) with
     ONE packed device->host copy (plus the (B+1)-entry offset table) instead of one copy per image."""
     B, max_out, W = rows.shape
-    compact = torch.empty((B * max_out, W), dtype=torch.float32, device=rows.device)
-    offsets = torch.empty((B + 1,), dtype=torch.int64, device=rows.device)
+    compact = _out(arena, "compact_rows", (B * max_out, W), torch.float32, rows.device)
+    offsets = _out(arena, "compact_offsets", (B + 1,), torch.int64, rows.device)
     _lib.check(LIB.yamd_compact_rows(rows.data_ptr(), counts.data_ptr(), B, max_out, W, compact.data_ptr(),
                                      offsets.data_ptr(), _lib.current_stream()), "compact_rows")
     off = offsets.cpu().tolist()
@@ -100,14 +132,14 @@ def non_max_suppression_with_point_conf(prediction: torch.Tensor, img_size: floa
 
 
 def decode_anchor_levels(raws: List[torch.Tensor], anchors, strides, img_size: int, kind: int, point_num: int = 0,
-                         clamp_points: bool = False) -> torch.Tensor:
+                         clamp_points: bool = False, arena: Optional[Arena] = None) -> torch.Tensor:
     """raws[i]: (B,h,w,na*C) float32 NHWC head logits, ordered like ``strides``.  Returns the merged
     (B, A, C) tensor of the reference's ``_forward`` (cxcywh, input pixels)."""
     B = raws[0].shape[0]
     na = len(anchors) // len(raws)
     C = raws[0].shape[-1] // na
     A = sum(na * r.shape[1] * r.shape[2] for r in raws)
-    out = torch.empty((B, A, C), dtype=torch.float32, device=raws[0].device)
+    out = _out(arena, "decoded", (B, A, C), torch.float32, raws[0].device)
     off = 0
     st = _lib.current_stream()
     for i, (r, s) in enumerate(zip(raws, strides)):
@@ -133,8 +165,8 @@ def decode_anchor_head(raw: torch.Tensor, anchors, stride: int, kind: int, point
     return out
 
 
-def decode_dfl(raws: List[torch.Tensor], strides, reg_max: int, nc: int, out_fmt: str, unit_conf: bool = False
-               ) -> torch.Tensor:
+def decode_dfl(raws: List[torch.Tensor], strides, reg_max: int, nc: int, out_fmt: str, unit_conf: bool = False,
+               arena: Optional[Arena] = None) -> torch.Tensor:
     """raws[i]: (B,h,w,4*reg_max+nc) float32 NHWC.  Returns (B, A, 5+nc): [box, max score, scores]; with
     ``unit_conf`` (YOLOv6 m/l, reg_max = 17 bins) column 4 is the constant 1.0."""
     B = raws[0].shape[0]
@@ -142,7 +174,7 @@ def decode_dfl(raws: List[torch.Tensor], strides, reg_max: int, nc: int, out_fmt
     for r in raws:
         _lib.require_gpu(r, torch.float32, "raw head")
     A = sum(r.shape[1] * r.shape[2] for r in raws)
-    out = torch.empty((B, A, 5 + nc), dtype=torch.float32, device=raws[0].device)
+    out = _out(arena, "decoded", (B, A, 5 + nc), torch.float32, raws[0].device)
     ptrs = (ctypes.c_void_p * n)(*[r.data_ptr() for r in raws])
     hs = (ctypes.c_int * n)(*[r.shape[1] for r in raws])
     ws = (ctypes.c_int * n)(*[r.shape[2] for r in raws])
@@ -153,8 +185,8 @@ def decode_dfl(raws: List[torch.Tensor], strides, reg_max: int, nc: int, out_fmt
     return out
 
 
-def decode_ltrb_points(raws: List[torch.Tensor], strides, point_num: int, nc: int, out_fmt: str, bins: int = 1
-                       ) -> torch.Tensor:
+def decode_ltrb_points(raws: List[torch.Tensor], strides, point_num: int, nc: int, out_fmt: str, bins: int = 1,
+                       arena: Optional[Arena] = None) -> torch.Tensor:
     """raws[i]: (B,h,w,4*bins+2P+nc) float32 NHWC [ltrb (bins > 1: 4 x bins DFL logits) | landmarks | cls].  Returns
     (B, A, 5+2P+nc): [box, 1.0, landmarks, scores] (luoyang/yolov6_face/YoloV6Face.py:42-58 and :66-74)."""
     B = raws[0].shape[0]
@@ -162,7 +194,7 @@ def decode_ltrb_points(raws: List[torch.Tensor], strides, point_num: int, nc: in
     for r in raws:
         _lib.require_gpu(r, torch.float32, "raw head")
     A = sum(r.shape[1] * r.shape[2] for r in raws)
-    out = torch.empty((B, A, 5 + 2 * point_num + nc), dtype=torch.float32, device=raws[0].device)
+    out = _out(arena, "decoded", (B, A, 5 + 2 * point_num + nc), torch.float32, raws[0].device)
     ptrs = (ctypes.c_void_p * n)(*[r.data_ptr() for r in raws])
     hs = (ctypes.c_int * n)(*[r.shape[1] for r in raws])
     ws = (ctypes.c_int * n)(*[r.shape[2] for r in raws])

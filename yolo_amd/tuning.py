@@ -33,7 +33,7 @@ def lookup(k: int, s: int, cin: int, cout: int, ho: int, wo: int) -> Optional[Tu
     t = table().get(key(k, s, cin, cout, ho, wo))
     if t is None:
         return None
-    return (int(t[0]), int(t[1]), int(t[2]), int(t[3]) if len(t) > 3 else 4)
+    return (int(t[0]), int(t[1]), int(t[2]), int(t[3]) if len(t) > 3 else 4, int(t[4]) if len(t) > 4 else 1)
 
 
 def candidates(k: int, s: int, cin: int, cout: int) -> List[Tuple[int, ...]]:
@@ -45,8 +45,9 @@ def candidates(k: int, s: int, cin: int, cout: int) -> List[Tuple[int, ...]]:
                 continue
             for ck in (16, 32, 64):
                 if cin % ck == 0:
-                    out.append((mrep, nrep, ck, 4))
-                    out.append((mrep, nrep, ck, 8))
+                    for nwaves in (4, 8):
+                        for stages in (1, 2):
+                            out.append((mrep, nrep, ck, nwaves, stages))
     return out
 
 

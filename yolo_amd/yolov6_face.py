@@ -336,13 +336,14 @@ class YoloV6Face(TaskModel):
         out = self.program().run(images)
         return [out[f"L{i}"] for i in range(self.param.num_layers)]
 
-    def _decode(self, raws, fmt: str) -> torch.Tensor:
+    def _decode(self, raws, fmt: str, arena=None) -> torch.Tensor:
         dfl = self.box_channels != 4
         if dfl and not self.point_num:
-            return torch_utils.decode_dfl(raws, self.param.strides, DFL_BINS, self.param.class_num, fmt, unit_conf=True)
+            return torch_utils.decode_dfl(raws, self.param.strides, DFL_BINS, self.param.class_num, fmt, unit_conf=True,
+                                          arena=arena)
         ncp = self.param.class_num + (self.point_num if self.point_conf else 0)
         return torch_utils.decode_ltrb_points(raws, self.param.strides, self.point_num, ncp, fmt,
-                                              bins=DFL_BINS if dfl else 1)
+                                              bins=DFL_BINS if dfl else 1, arena=arena)
 
     def _forward(self, images: torch.Tensor) -> List[torch.Tensor]:
         """[(B, A, 5+2P+nc)]: cxcywh, 1.0, landmarks, class scores (YoloV6Face.py:42-58)."""
@@ -371,12 +372,13 @@ class YoloV6Face(TaskModel):
         tensor_dict["_pred_xyxy"] = pred
         return tensor_dict
 
-    def decode_predict(self, raws) -> torch.Tensor:
-        return self._decode(raws, "xyxy")
+    def decode_predict(self, raws, arena=None) -> torch.Tensor:
+        return self._decode(raws, "xyxy", arena=arena)
 
-    def nms_predict(self, pred: torch.Tensor):
+    def nms_predict(self, pred: torch.Tensor, arena=None):
         rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "xyxy", self.param.conf_threshold,
-                                                  self.param.nms_threshold, (3 if self.point_conf else 2) * self.point_num)
+                                                  self.param.nms_threshold, (3 if self.point_conf else 2) * self.point_num,
+                                                  arena=arena)
         return rows, counts
 
     def predict(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:

@@ -146,9 +146,9 @@ class YoloV8(TaskModel):
         out = self.program().run(images)
         return [out["L0"], out["L1"], out["L2"]]
 
-    def _decode(self, raws, fmt: str, strides=None) -> torch.Tensor:
+    def _decode(self, raws, fmt: str, strides=None, arena=None) -> torch.Tensor:
         return torch_utils.decode_dfl(raws, self.param.strides if strides is None else strides, REG_MAX,
-                                      self.param.class_num, fmt)
+                                      self.param.class_num, fmt, arena=arena)
 
     def _forward(self, images: torch.Tensor) -> List[torch.Tensor]:
         """[(B, A, 5+nc)]: cxcywh in input pixels, max class score, class scores (YoloV8.py:39-57)."""
@@ -173,12 +173,12 @@ class YoloV8(TaskModel):
         tensor_dict.pop("_raw_heads")
         return tensor_dict
 
-    def decode_predict(self, raws) -> torch.Tensor:
-        return self._decode(raws, "xyxy")
+    def decode_predict(self, raws, arena=None) -> torch.Tensor:
+        return self._decode(raws, "xyxy", arena=arena)
 
-    def nms_predict(self, pred: torch.Tensor):
+    def nms_predict(self, pred: torch.Tensor, arena=None):
         rows, counts, _ = torch_utils.nms_batched(pred, self.param.img_size, "xyxy", self.param.conf_threshold,
-                                                  self.param.nms_threshold)
+                                                  self.param.nms_threshold, arena=arena)
         return rows, counts
 
     def predict(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:
