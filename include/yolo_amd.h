@@ -208,6 +208,20 @@ int yamd_nms_batched(const float *pred, int batch, int a, int c, int in_cxcywh, 
                      float conf_thr, double iou_thr, float *out_rows, int *out_index, int max_out,
                      int *out_counts, void *workspace, size_t workspace_bytes, void *stream);
 
+/* yamd_nms_batched for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc): the same kernels, with the workspace taken from a static device array of the
+ * library instead of a caller buffer, so the call allocates and frees nothing.  No counterpart in the reference.
+ *   - the array holds yamd_nms_static_capacity_bytes() = 16 MiB on every GPU the library runs on, for the life of the
+ *     process; a shape whose yamd_nms_workspace_bytes() exceeds that is refused with YAMD_ENOSPC (16 MiB covers e.g.
+ *     8 images x 25 200 anchors; larger batches use yamd_nms_batched with their own workspace);
+ *   - all calls on one GPU share that array: calls that overlap in time on one GPU (different streams or host
+ *     threads) race; calls ordered on one stream are safe, each clears the counters it needs itself.
+ * Inputs, outputs and semantics are those of yamd_nms_batched. */
+size_t yamd_nms_static_capacity_bytes(void);
+int yamd_nms_batched_static(const float *pred, int batch, int a, int c, int in_cxcywh, int n_extra, float img_size,
+                            float conf_thr, double iou_thr, float *out_rows, int *out_index, int max_out,
+                            int *out_counts, void *stream);
+
 /* Packs the kept rows of all images back to back for a single device->host copy; the counterpart of
  * the per-image `.detach().cpu().numpy()` of yolov5/YoloV5.py:125-126.  compact: (sum_b min(count_b,
  * max_out), width) float; offsets: (batch+1) int64, offsets[b] = first row of image b, offsets[batch] =

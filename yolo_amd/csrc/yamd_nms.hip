@@ -912,7 +912,30 @@ extern "C" size_t yamd_nms_workspace_bytes(int batch, int a, int c, int n_extra)
     return ws_layout(batch, a, nc).total;
 }
 
+// Static scratch of yamd_nms_batched_static: one copy per GPU for the life of the process.  The name is a host-side
+// handle only; the per-device address comes from hipGetSymbolAddress (scratch_for_current_device).
+#define YAMD_NMS_STATIC_BYTES (16u << 20)
+static __device__ __align__(256) unsigned char scratch[YAMD_NMS_STATIC_BYTES];
+
 namespace {
+constexpr int MAX_DEVICES = 64;
+std::atomic<void *> g_scratch_ptr[MAX_DEVICES];
+
+int scratch_for_current_device(void **out)
+{
+    int dev = 0;
+    YAMD_HIP(hipGetDevice(&dev));
+    YAMD_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "device ordinal %d outside [0, %d)", dev, MAX_DEVICES);
+    void *ptr = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (ptr == nullptr) {
+        YAMD_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));   // this device's copy (the device is current)
+        YAMD_REQUIRE(ptr != nullptr && ((uintptr_t)ptr % 256) == 0, "static scratch has no usable device address");
+        g_scratch_ptr[dev].store(ptr, std::memory_order_release);    // every thread resolves the same address
+    }
+    *out = ptr;
+    return YAMD_OK;
+}
+
 int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, int n_extra, float img_size, float conf_thr,
                      double iou_thr, float *out_rows, int *out_index, int max_out, int *out_counts, void *workspace,
                      size_t workspace_bytes, void *stream);
@@ -925,7 +948,9 @@ int nms_init_current_device(int device)
     int rc = KernelAttr<&nms_filter_kernel, 160 * 1024>::ensure();
     if (rc == YAMD_OK) rc = KernelAttr<&nms_segment_kernel, 160 * 1024>::ensure();
     if (rc == YAMD_OK) rc = KernelAttr<&nms_gather_sort_kernel, 150 * 1024>::ensure();
-    return rc;
+    if (rc != YAMD_OK) return rc;
+    void *ptr = nullptr;
+    return scratch_for_current_device(&ptr);
 }
 }  // namespace yamd
 
@@ -936,6 +961,28 @@ extern "C" int yamd_nms_batched(const float *pred, int batch, int a, int c, int 
     YAMD_REQUIRE(workspace, "null argument");
     return nms_batched_impl(pred, batch, a, c, in_cxcywh, n_extra, img_size, conf_thr, iou_thr, out_rows, out_index, max_out,
                             out_counts, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t yamd_nms_static_capacity_bytes(void) { return YAMD_NMS_STATIC_BYTES; }
+
+extern "C" int yamd_nms_batched_static(const float *pred, int batch, int a, int c, int in_cxcywh, int n_extra, float img_size,
+                                       float conf_thr, double iou_thr, float *out_rows, int *out_index, int max_out,
+                                       int *out_counts, void *stream)
+{
+    const int nc = c - 5 - n_extra;
+    YAMD_REQUIRE(batch > 0 && a > 0 && n_extra >= 0 && nc > 0, "bad shape B=%d A=%d C=%d extra=%d", batch, a, c, n_extra);
+    const size_t need = ws_layout(batch, a, nc).total;
+    if (need > YAMD_NMS_STATIC_BYTES) {
+        set_error("yamd_nms_batched_static: batch %d x %d anchors x %d classes needs %zu bytes of scratch, the static array "
+                  "holds %u; use yamd_nms_batched with a caller-owned workspace",
+                  batch, a, nc, need, (unsigned)YAMD_NMS_STATIC_BYTES);
+        return YAMD_ENOSPC;
+    }
+    void *ptr = nullptr;
+    const int rc = scratch_for_current_device(&ptr);
+    if (rc != YAMD_OK) return rc;
+    return nms_batched_impl(pred, batch, a, c, in_cxcywh, n_extra, img_size, conf_thr, iou_thr, out_rows, out_index, max_out,
+                            out_counts, ptr, YAMD_NMS_STATIC_BYTES, stream);
 }
 
 namespace {
