@@ -158,6 +158,14 @@ int yamd_decode_anchor(int kind, const float *raw, int batch, int h, int w, int 
                        int clamp_points, float *out, long long rows_per_image, long long row_offset,
                        void *stream);
 
+/* All pyramid levels of an anchor head in one launch, merged form only (merge == 1 above): raw[i] is
+ * (batch,h_i,w_i,na*c) float NHWC, anchors_wh_host holds n_levels*na*2 floats (level-major), out is
+ * (batch, na * sum h_i*w_i, c) with the levels in the given order (yolov5/YoloV5.py:60-69, yolov3/YoloV3.py:129-139,
+ * yolov7_pose/YoloV7Pose.py:143-159).  n_levels <= 8, na <= 4. */
+int yamd_decode_anchor_levels(int kind, const float *const *raw_host_ptrs, const int *hs_host, const int *ws_host,
+                              const int *strides_host, const float *anchors_wh_host, int n_levels, int batch, int na,
+                              int c, int point_num, float img_size, int clamp_points, float *out, void *stream);
+
 /* Anchor-free DFL decode, one call for all levels (yolov8/YoloV8Head.py:28-60, YoloV8Body.py:204-223,
  * utils/torch_utils.py:373-394, yolov8/YoloV8.py:48-57 and :118-124).  raw[i]: (batch,h_i,w_i,4*reg_max+nc)
  * float NHWC, channel order [reg 4*reg_max | cls nc].  out: (batch, sum h_i*w_i, 5+nc) =

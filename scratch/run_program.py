@@ -1,0 +1,31 @@
+"""Runs only the conv program of a model (no decode / NMS), `reps` times at one batch size, and writes the recorded op
+list with its algorithmic flops / bytes: the subject of the per-layer counter passes (scratch/layer_counters.sh).
+python3 scratch/run_program.py <model> <batch> <reps> <ops.json>"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from yolo_amd import models
+from yolo_amd.init import seeded_state_dict
+
+name, B, reps, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+p, m = models.create(name)
+m.load_state_dict(seeded_state_dict(m, seed=0, mode="torch_default"))
+dev = torch.device("cuda:0")
+x = torch.rand(B, 3, p.img_size, p.img_size, device=dev)
+prog = m.program()
+for _ in range(reps):
+    prog.run(x)
+torch.cuda.synchronize()
+ops = []
+for op in prog.ops:
+    fl, by = prog.op_cost(op, B)
+    kind = op[0]
+    name_ = getattr(op[1], "name", kind) if kind in ("conv", "stem") else kind
+    desc = ""
+    if kind == "conv":
+        d = op[1].desc
+        o = op[3]
+        desc = f"k{d.ksize}s{d.stride} {d.cin}>{d.cout} @{o.h}x{o.w} tiling={op[1].tiling}"
+    launches = 1
+    ops.append(dict(kind=kind, name=name_, desc=desc, flops=fl, bytes=by))
+json.dump(dict(model=name, batch=B, reps=reps, ops=ops), open(out, "w"))

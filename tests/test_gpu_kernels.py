@@ -245,6 +245,36 @@ def test_conv_tilings(gpu_device, k, s, cin, cout, H, W, use_res, tiling):
     assert float(err.abs().max()) <= 1.5e-2 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("k,s,cin,cout,H,W,use_res,tiling", [
+    (3, 1, 64, 128, 20, 20, True, (1, 4, 16, 4, 1)),      # 128-pixel tiles of 6 rows over 5 stacked 20-row images
+    (3, 1, 64, 128, 19, 19, False, (2, 4, 16, 4, 1)),
+    (3, 1, 64, 128, 19, 19, True, (2, 4, 32, 8, 1)),      # 512-pixel tiles: every tile spans two images
+    (3, 1, 32, 64, 10, 12, True, (1, 2, 32, 8, 1)),
+    (3, 2, 64, 128, 40, 40, False, (2, 4, 16, 4, 1)),     # stride 2: two zero rows between the stacked images
+    (3, 2, 64, 128, 38, 38, False, (1, 4, 16, 4, 1)),
+    (3, 2, 32, 64, 12, 20, False, (1, 2, 16, 8, 1)),
+])
+def test_conv_small_maps_stacked_images(gpu_device, k, s, cin, cout, H, W, use_res, tiling):
+    """Small feature maps: the launcher tiles the whole batch as one tall image (zero rows between the images), so
+    tiles straddle images; every image, the first and last rows of each in particular, must still equal the
+    per-image convolution."""
+    g = torch.Generator().manual_seed(k * 91 + cin + cout + H + W + sum(tiling))
+    Bn = 5
+    x = _bf16_round(torch.randn((Bn, cin, H, W), generator=g))
+    w = _bf16_round(torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5)
+    b = torch.randn((cout,), generator=g) * 0.5
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    res = _bf16_round(torch.randn((Bn, cout, Ho, Wo), generator=g)) if use_res else None
+    want = _act(F.conv2d(x, w, b, stride=s, padding=k // 2), 1)
+    if res is not None:
+        want = want + res
+    got = _run_conv(gpu_device, x, w, b, k, s, 1, res, False, in_extra=16, out_extra=8, tiling=tiling)
+    for i in range(Bn):
+        err = (got[i] - want[i]).double()
+        assert float(err.norm() / want[i].double().norm()) <= 4e-3, f"image {i}"
+        assert float(err.abs().max()) <= 1.5e-2 * float(want.abs().max()), f"image {i}"
+
+
 def test_conv_identity_asymmetric(gpu_device):
     """1x1 identity weights with an asymmetric input: catches any row/column or k-order permutation exactly."""
     cin = cout = 64

@@ -9,6 +9,8 @@ bf16 tolerances (weights and activations rounded to bf16 through the whole conv 
 The kept set is compared by matching (same class, IoU > 0.9), because bf16 noise legitimately flips
 threshold decisions; NMS itself is bit-exact given identical input (test_gpu_postprocess.py).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -79,11 +81,13 @@ def test_small_vs_reference_golden(name, gpu_device):
             assert a is None or a.shape[0] <= 2
             continue
         assert a is not None and a.shape[1] == b.shape[1] and a.dtype == np.float32
-        assert abs(a.shape[0] - b.shape[0]) <= max(3, 0.1 * b.shape[0])
+        assert abs(a.shape[0] - b.shape[0]) <= max(3, 0.03 * b.shape[0])
+        # measured: 0.976 .. 1.0 for every model except v6m, whose 11 reference rows leave one unmatched (0.909)
+        floor = 0.9 if name == "v6m" else 0.95
         if name in ("v6face", "v6", "v6pose", "v6facen", "v6m", "v6l", "v6facem", "v6posel"):
-            assert _match_rows_abs(a, b, 3.0) >= 0.8
+            assert _match_rows_abs(a, b, 3.0) >= floor
         else:
-            assert _match_rows(a, b) >= 0.8
+            assert _match_rows(a, b) >= floor
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -205,3 +209,46 @@ def test_full_batch_properties(name, gpu_device):
             continue
         assert counts[b] == want[b].shape[0]
         assert np.array_equal(r0[b, :counts[b]].view(np.uint32), want[b].view(np.uint32))
+
+
+def test_service_predict_from_config_json(gpu_device, tmp_path):
+    """ServicePredict.YoloPredict shape: init_model(model_dir) reads config.json (the reference's keys) and the
+    checkpoint named there; predict(feed_dicts) takes raw images (array, PIL or base64) and returns boxes in the
+    original image + label names, equal to letterbox -> model.predict -> RestoreSize done by hand."""
+    import base64
+    import json
+    import shutil
+    from io import BytesIO
+    from PIL import Image
+    from conftest import GOLDEN
+    from yolo_amd import service
+    from yolo_amd.transformer import RestoreSize, letterbox_batch
+    p, m, sd = _model("v5s", 64, 11)
+    shutil.copy(os.path.join(GOLDEN, "service", "config.json"), tmp_path / "config.json")
+    torch.save(sd, tmp_path / "yolov5s.pth")
+    cfg = json.load(open(tmp_path / "config.json"))
+    rng = np.random.RandomState(4)
+    imgs = [rng.randint(0, 256, (48, 80, 3), dtype=np.uint8), rng.randint(0, 256, (100, 60, 3), dtype=np.uint8),
+            rng.randint(0, 256, (64, 64, 3), dtype=np.uint8)]
+    buf = BytesIO()
+    Image.fromarray(imgs[1]).save(buf, format="PNG")
+    feeds = [{"image": imgs[0]}, {"image": base64.b64encode(buf.getvalue()).decode()}, {"image": Image.fromarray(imgs[2])}]
+    sp = service.YoloPredict(gpu_id=0)
+    sp.init_model(model_dir=str(tmp_path), batch_size=2)
+    assert sp.input_size == (64, 64) and sp.labels == cfg["lables"] and sp.outputs == ["head_predicts"]
+    got = sp.predict(feeds)
+    x, metas = letterbox_batch(imgs, 64, 64, device=gpu_device)
+    want = m.predict({"batch_images": x})["predicts"]
+    assert len(got) == 3 and any(w is not None for w in want)
+    for g, w, meta in zip(got, want, metas):
+        d = dict(meta, predict=w)
+        RestoreSize().transformer(d)
+        boxes = d["predict_boxs"]
+        assert g["predict_boxs"] == (boxes.tolist() if isinstance(boxes, np.ndarray) else [])
+        assert g["predict_label"] == [cfg["lables"][i] for i in d["predict_label"]]
+    cfg["nms"] = False
+    json.dump(cfg, open(tmp_path / "config.json", "w"))
+    sp2 = service.YoloPredict(gpu_id=0)
+    sp2.init_model(model_dir=str(tmp_path))
+    with pytest.raises(NotImplementedError):
+        sp2.predict(feeds[:1])

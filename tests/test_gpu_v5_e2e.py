@@ -85,8 +85,8 @@ def test_v5s_64_vs_reference_golden(gpu_device):
     want = split_rows(g["counts"], g["rows"])
     for a, b in zip(out, want):
         assert a.shape[1] == 7 and a.dtype == np.float32
-        assert abs(a.shape[0] - b.shape[0]) <= max(3, 0.1 * b.shape[0])
-        assert _match_rows(a, b) >= 0.85
+        assert abs(a.shape[0] - b.shape[0]) <= max(3, 0.03 * b.shape[0])
+        assert _match_rows(a, b) >= 0.95
 
 
 def test_v5s_fused_equals_unfused(gpu_device):
@@ -151,3 +151,40 @@ def test_full_batch_properties(gpu_device):
         assert counts[b] == want[b].shape[0]
         assert np.array_equal(r0[b, :counts[b]].view(np.uint32), want[b].view(np.uint32))
         assert np.array_equal(idx[b, :counts[b]].astype(np.int64), want_idx[b])
+
+
+def test_v5s_layer_by_layer_vs_oracle(gpu_device):
+    """Per-layer gate: every checked layer (or block) is re-computed by the fp32 CPU oracle FROM THE GPU's OWN INPUT of
+    that layer, so the difference is that layer's bf16 rounding alone: relative L2 <= 1e-2 for single convs of every
+    kind (stem from the image, 3x3 stride 2, 1x1, the SPP block with its pools, the fp32 head conv) and for whole C3
+    blocks (four to eight convs chained)."""
+    import torch.nn.functional as F
+    from oracle import v5_ref as R
+    from yolo_amd.init import seeded_images, seeded_state_dict
+    p, m = _model(128, 21, gpu_device)
+    sd = seeded_state_dict(m, seed=21, mode="spread")
+    imgs_np = seeded_images(2, 128, seed=21)
+    imgs = torch.from_numpy(imgs_np)
+    raws = m.raw_heads(imgs.to(gpu_device))
+    prog = m.program()
+    tap = {k: prog.read_view(v, 2, gpu_device).cpu() for k, v in prog.taps.items()}
+    bb, n = "body_net.backbone.", "body_net."
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        focus = torch.cat((imgs[..., ::2, ::2], imgs[..., 1::2, ::2], imgs[..., ::2, 1::2], imgs[..., 1::2, 1::2]), 1)
+        checks = {
+            "stem": (R._conv_block(sd, bb + "stem.conv", focus.bfloat16().float()), tap["stem"]),
+            "dark2.0 (3x3 s2)": (R._conv_block(sd, bb + "dark2.0", tap["stem"], 2), tap["dark2.0"]),
+            "dark2.1 (C3)": (R._c3(sd, bb + "dark2.1", tap["dark2.0"], True), tap["dark2"]),
+            "dark3.0 (3x3 s2)": (R._conv_block(sd, bb + "dark3.0", tap["dark2"], 2), tap["dark3.0"]),
+            "dark3.1 (C3 x3)": (R._c3(sd, bb + "dark3.1", tap["dark3.0"], True), tap["feat1"]),
+            "dark5.0 (3x3 s2)": (R._conv_block(sd, bb + "dark5.0", tap["feat2"], 2), tap["dark5.0"]),
+            "dark5.1 (SPP)": (R._spp(sd, bb + "dark5.1", tap["dark5.0"]), tap["spp"]),
+            "dark5.2 (C3)": (R._c3(sd, bb + "dark5.2", tap["spp"], False), tap["feat3"]),
+            "conv_for_feat3 (1x1)": (R._conv_block(sd, n + "conv_for_feat3", tap["feat3"]), tap["p5_lateral"]),
+            "down_sample1 (3x3 s2)": (R._conv_block(sd, n + "down_sample1", tap["p3"], 2), tap["down_sample1"]),
+            "yolo_head_P3 (fp32 out)": (F.conv2d(tap["p3"], sd[n + "yolo_head_P3.weight"], sd[n + "yolo_head_P3.bias"]),
+                                        raws[0].cpu().permute(0, 3, 1, 2)),
+        }
+    worst = {k: _rel_l2(got.numpy(), want.numpy()) for k, (want, got) in checks.items()}
+    assert max(worst.values()) <= 1e-2, worst

@@ -202,6 +202,25 @@ int conv_impl(const yamd_conv_desc *d, const void *x, int x_cstride, const void 
         YAMD_REQUIRE(y_cstride >= d->cout && residual == nullptr, "float output: cstride=%d, no residual", y_cstride);
     }
     const int KS = d->ksize, S = d->stride, pad = KS / 2;
+    // A 1x1 conv does not look at the image geometry, and consecutive pixels (also across rows and images) are
+    // x_cstride apart everywhere, so the batch is re-read as few, very tall images whose width equals the tile width:
+    // every tile is then full except the last one of each image, whatever the real height and width (20x20 and 40x40
+    // maps fill only 78 % / 89 % of their own 128- or 256-pixel tiles).
+    if (KS == 1) {
+        const long long px = (long long)batch * h * w;
+        const int tw = (w % 20 == 0 && w % 16 != 0) ? 20 : 16;
+        if (px % tw == 0) {
+            // split into the fewest images that stay below 2^31 elements each (32-bit offsets inside an image)
+            const long long widest = x_cstride > y_cstride ? x_cstride : y_cstride;
+            long long parts = 1;
+            while (parts <= batch && ((px / parts) * widest >= (1ll << 31) || px % (parts * tw) != 0 || batch % parts != 0)) ++parts;
+            if (parts <= batch) {
+                batch = (int)parts;
+                h = (int)(px / parts / tw);
+                w = tw;
+            }
+        }
+    }
     ConvParams p;
     p.x = (const __bf16 *)x;
     p.w = (const char *)w_packed;
@@ -226,6 +245,23 @@ int conv_impl(const yamd_conv_desc *d, const void *x, int x_cstride, const void 
     p.tiles_x = ceil_div(p.Wout, TW);
     p.tiles_y = ceil_div(p.Hout, th_max);
     p.TH = ceil_div(p.Hout, p.tiles_y);
+    p.vin = p.vout = p.vbatch = 0;
+    // 3x3 convs on small maps: when whole-image tiling leaves tile rows empty, stack the images (see ConvParams) if that
+    // needs at least 8 % fewer workgroups
+    if (KS == 3 && !d->out_f32 && batch > 1 && (S == 1 || h % 2 == 0) &&
+        (long long)batch * h * w * x_cstride < (1ll << 31) && (long long)batch * (h + 2) < (1 << 24)) {
+        const int vout = p.Hout + 1;
+        const long long plain = (long long)batch * p.tiles_y;
+        const long long stacked = ceil_div((long long)batch * vout, th_max);
+        if (stacked * 100 <= plain * 92) {
+            p.vin = S == 1 ? h + 1 : h + 2;
+            p.vout = vout;
+            p.vbatch = batch;
+            p.TH = th_max;
+            p.tiles_y = (int)stacked;
+            batch = 1;
+        }
+    }
     p.n_tiles = d->cout_pad / (d->nrep * 32);
     p.nchunks = d->cin / d->ck;
     hipStream_t st = (hipStream_t)stream;

@@ -16,6 +16,12 @@
 // (mod 16) per LDS cycle, so the fragment reads are bank-conflict free; the staging writes
 // (4..8 consecutive 16-byte pieces per pixel) are too.  For stride 2 the halo columns are stored
 // de-interleaved (even columns first) so that the 32 pixels of a fragment are again consecutive.
+//
+// Stride 2 with 16-channel chunks uses a compact image instead (ConvLds<...>::COMPACT): 32 bytes per pixel without
+// padding, halo rows CROW pixels apart, and the two 16-byte halves of a pixel swapped where swz() says so.  The halo
+// of a stride-2 tile is four times the tile, so the padding bytes decide whether two workgroups fit a compute unit;
+// row pitch, even/odd column split and swizzle were found by exhaustive search over the lane groups of ds_read_b128
+// (conflict free for every tap and fragment, both tile widths).
 #pragma once
 #include "yamd_common.h"
 
@@ -40,6 +46,11 @@ struct ConvParams {
     int TH, tiles_x, tiles_y, n_tiles, nchunks;
     int act;
     int total_tiles;
+    // stacked mode (3x3, bf16 output): the images of the batch are treated as ONE tall image, `vin` input rows and
+    // `vout` output rows per image (the real rows followed by 1 or 2 rows of zero padding, which is exactly the
+    // padding the neighbouring images need), so tiles are not confined to one image and small feature maps still
+    // fill them.  0 = off.
+    int vin, vout, vbatch;
     float res_scale;             // weight of the residual in the sum
 #ifdef YAMD_CONV_TRACE
     unsigned long long *trace;   // 8 timestamps per workgroup (profiling builds only)
@@ -81,6 +92,19 @@ __device__ __forceinline__ float apply_act(float v, int act)
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>); every array index
 // inside f is a constant, so staging arrays stay in registers
+// geometry of the LDS activation image shared by the kernel and its launcher
+template <int KS, int S, int TW, int CK>
+struct ConvLds {
+    static constexpr int NPW = (TW - 1) * S + KS;            // halo width in input pixels
+    static constexpr bool COMPACT = (S == 2 && CK == 16 && KS == 3 && (TW == 16 || TW == 20));
+    static constexpr int NPWH = COMPACT ? (TW == 16 ? 17 : 21) : (NPW + 1) / 2;     // first odd column (stride-2 de-interleave)
+    static constexpr int CROW = TW == 16 ? 34 : 42;          // compact image: pixels per halo row
+    static constexpr int RS = CK * 2 + 16;                   // padded image: bytes per halo pixel
+    static __host__ __device__ constexpr int image_bytes(int nph) { return COMPACT ? nph * CROW * 32 : nph * NPW * RS; }
+    // compact image: 1 where the two 16-byte halves of the pixel at (halo row r, stored column c) are swapped
+    static __device__ __forceinline__ int swz(int r, int c) { return TW == 16 ? ((c >> 2) & 1) : (((r * CROW + c) >> 3) & 1); }
+};
+
 template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f)
 {
@@ -105,9 +129,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
 {
     constexpr int NT = NW * 64;              // threads per workgroup (4 or 8 waves share one weight tile)
     constexpr int PAD = KS / 2;
-    constexpr int NPW = (TW - 1) * S + KS;   // halo width in input pixels
-    constexpr int NPWH = (NPW + 1) / 2;      // even-column count (stride-2 de-interleave)
-    constexpr int RS = CK * 2 + 16;          // LDS bytes per halo pixel
+    using Lds = ConvLds<KS, S, TW, CK>;
+    constexpr int NPW = Lds::NPW;            // halo width in input pixels
+    constexpr int NPWH = Lds::NPWH;          // first odd column (stride-2 de-interleave)
+    constexpr int RS = Lds::RS;              // LDS bytes per halo pixel (padded image)
+    constexpr bool COMPACT = Lds::COMPACT;
+    constexpr int CROW = Lds::CROW;
     constexpr int G8 = CK / 8;               // 16-byte pieces per halo pixel
     constexpr int KSTEPS = CK / 16;
     constexpr int TAPS = KS * KS;
@@ -135,13 +162,26 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
     const int c32 = lane & 31, g = lane >> 5;
 
     // LDS byte offset of this lane's pixel (tap 0,0) for each 32-pixel fragment
+    // compact image: pixoff is the byte offset of the pixel at tap (0,0) without the half select; bit (m*9 + tap) of
+    // halfsel says which 16-byte half of that tap's pixel holds this lane's k-group
+    static_assert(!COMPACT || MREP * TAPS <= 32, "one half-select bit per (fragment, tap)");
     int pixoff[MREP];
+    unsigned halfsel = 0u;
 #pragma unroll
     for (int m = 0; m < MREP; ++m) {
         const int pp = wave * (32 * MREP) + m * 32 + c32;
         int pr = pp / TW, pc = pp % TW;
         if (pr >= p.TH) { pr = 0; pc = 0; }   // slot beyond the tile: read something valid, never stored
-        pixoff[m] = ((pr * S) * NPW + pc) * RS + g * 16;
+        if constexpr (COMPACT) {
+            pixoff[m] = ((pr * S) * CROW + pc) * 32;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int r = pr * S + tap / KS, c = pc + ((tap % KS) & 1) * NPWH + ((tap % KS) >> 1);
+                halfsel |= (unsigned)(g ^ Lds::swz(r, c)) << (m * TAPS + tap);
+            }
+        } else {
+            pixoff[m] = ((pr * S) * NPW + pc) * RS + g * 16;
+        }
     }
 
     // Staging registers: the next chunk's global loads are issued before the current chunk is computed
@@ -164,12 +204,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
         const int q = min(tid + u * NT, total - 1);
         const int pix = q / G8, gc = q % G8;
         const int hr = pix / NPW, hc = pix % NPW;
-        const int ih = oh0 * S - PAD + hr, iw = ow0 * S - PAD + hc;
-        const bool inb = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+        int ih = oh0 * S - PAD + hr;
+        const int iw = ow0 * S - PAD + hc;
+        bool inb = iw >= 0 && iw < p.W;
+        int img_row0 = 0;                               // stacked mode: first row of the piece's image in the batch
+        if (p.vin > 0) {
+            const int vb = ih >= 0 ? ih / p.vin : -1;
+            ih -= vb * p.vin;                           // row inside the image (or its zero rows)
+            inb = inb && vb >= 0 && vb < p.vbatch;
+            img_row0 = min(max(vb, 0), p.vbatch - 1) * p.H;
+        }
+        inb = inb && ih >= 0 && ih < p.H;
         const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
-        goff[u] = (ihc * p.W + iwc) * p.x_cs + gc * 8;
+        goff[u] = ((img_row0 + ihc) * p.W + iwc) * p.x_cs + gc * 8;
         const int lc = (S == 2) ? ((hc & 1) * NPWH + (hc >> 1)) : hc;
-        loff[u] = (hr * NPW + lc) * RS + gc * 16;
+        if constexpr (COMPACT) loff[u] = (hr * CROW + lc) * 32 + ((gc ^ Lds::swz(hr, lc)) << 4);
+        else loff[u] = (hr * NPW + lc) * RS + gc * 16;
         inb_mask |= inb ? (1u << u) : 0u;
     });
     const __bf16 *ximg = p.x + (size_t)b * p.H * p.W * p.x_cs;
@@ -188,7 +238,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
             ra[u] = ((inb_mask >> u) & 1u) ? v : u32x4{0u, 0u, 0u, 0u};
         });
     };
-    const int stage_bytes = WBYTES + NPH * NPW * RS;          // one LDS image: weights, then the halo tile (multiple of 16)
+    const int stage_bytes = WBYTES + Lds::image_bytes(NPH);   // one LDS image: weights, then the halo tile (multiple of 16)
     auto write_lds = [&](int stage) __attribute__((always_inline)) {
         char *ldsW = smem + stage * stage_bytes;
         char *ldsA = ldsW + WBYTES;
@@ -229,6 +279,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
         if (more) issue_loads(ch + 1);
         const char *ldsW = smem + (STAGES == 2 ? (ch & 1) * stage_bytes : 0);
         const char *ldsA = ldsW + WBYTES;
+        // compact image: the per-tap half selects are re-derived from one register in every chunk; hoisted out of the
+        // loop they would occupy one address register per (fragment, tap)
+        unsigned hs = halfsel;
+        if constexpr (COMPACT) asm volatile("" : "+v"(hs));
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int kh = tap / KS, kw = tap % KS;
@@ -237,7 +291,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 bf16x8 a[MREP], wv[NREP];
 #pragma unroll
-                for (int m = 0; m < MREP; ++m) a[m] = *(const bf16x8 *)(ldsA + pixoff[m] + tapoff + ks * 32);
+                for (int m = 0; m < MREP; ++m) {
+                    if constexpr (COMPACT) {
+                        const int tapc = (kh * CROW + (kw & 1) * NPWH + (kw >> 1)) * 32;
+                        a[m] = *(const bf16x8 *)(ldsA + pixoff[m] + tapc + (((hs >> (m * TAPS + tap)) & 1u) << 4));
+                    } else {
+                        a[m] = *(const bf16x8 *)(ldsA + pixoff[m] + tapoff + ks * 32);
+                    }
+                }
 #pragma unroll
                 for (int n = 0; n < NREP; ++n)
                     wv[n] = *(const bf16x8 *)(ldsW + ((tap * KSTEPS + ks) * NREP + n) * 1024 + lane * 16);
@@ -365,8 +426,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
             constexpr int ACT = decltype(ac)::value;
             const int pp = wave * (32 * MREP) + m * 32 + c32;
             const int pr = pp / TW, pc = pp % TW;
-            const bool valid = pr < p.TH && oh0 + pr < p.Hout && ow0 + pc < p.Wout;
-            const size_t pix = (size_t)(b * p.Hout + oh0 + pr) * p.Wout + ow0 + pc;
+            int orow = oh0 + pr, obase = b * p.Hout;      // output row inside its image, first output row of the image
+            bool valid = pr < p.TH && ow0 + pc < p.Wout;
+            if (p.vout > 0) {
+                const int vb = orow / p.vout;
+                orow -= vb * p.vout;
+                valid = valid && vb < p.vbatch;
+                obase = vb * p.Hout;
+            }
+            valid = valid && orow < p.Hout;
+            const size_t pix = (size_t)(obase + orow) * p.Wout + ow0 + pc;
             // residual: all loads of this fragment are issued up front (clamped address instead of a divergent
             // branch), so the epilogue pays one memory latency, not one per register quad
             const bool has_res = p.res != nullptr;      // uniform
@@ -410,8 +479,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
                 const int pq = wave * (32 * MREP) + m * 32 + r;
                 const int qr = pq / TW, qc = pq % TW;
                 const int co = nt * (NREP * 32) + piece * 8;
-                if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout && co < p.Cout) {
-                    const size_t opix = (size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc;
+                int srow = oh0 + qr, sbase = b * p.Hout;
+                bool sok = qr < p.TH && ow0 + qc < p.Wout && co < p.Cout;
+                if (p.vout > 0) {
+                    const int vb = srow / p.vout;
+                    srow -= vb * p.vout;
+                    sok = sok && vb < p.vbatch;
+                    sbase = vb * p.Hout;
+                }
+                if (sok && srow < p.Hout) {
+                    const size_t opix = (size_t)(sbase + srow) * p.Wout + ow0 + qc;
                     __bf16 *dst = co < p.split ? (__bf16 *)p.y + opix * p.y_cs + co : p.y2 + opix * p.y2_cs + (co - p.split);
                     *(uint4 *)dst = v;
                 }
@@ -422,8 +499,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
         // ACTK >= 0: the activation is a compile-time constant of this kernel (small code); ACTK < 0: one
         // uniform branch on the activation kind for the whole epilogue
         auto run = [&](auto ac) __attribute__((always_inline)) {
-            epilogue(std::integral_constant<int, 0>{}, ac);
-            if constexpr (MREP > 1) epilogue(std::integral_constant<int, 1>{}, ac);
+            static_for<MREP>([&](auto mc) __attribute__((always_inline)) { epilogue(mc, ac); });
         };
         if constexpr (ACTK >= 0) {
             run(std::integral_constant<int, ACTK>{});
@@ -443,11 +519,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
 template <int KS, int S, int TW, int MREP, int NREP, int CK, bool OUT_F32, int ACTK, int NW = 4, int STAGES = 1>
 int launch_conv(const ConvParams &p, int batch, hipStream_t stream)
 {
-    constexpr int NPW = (TW - 1) * S + KS;
-    constexpr int RS = CK * 2 + 16;
     constexpr int WBYTES = KS * KS * (CK / 16) * NREP * 1024;
     const int NPH = (p.TH - 1) * S + KS;
-    size_t lds = ((size_t)WBYTES + (size_t)NPH * NPW * RS) * STAGES;
+    size_t lds = ((size_t)WBYTES + (size_t)ConvLds<KS, S, TW, CK>::image_bytes(NPH)) * STAGES;
     const size_t epi = (size_t)NW * 32 * (OUT_F32 ? NREP * 128 + 16 : NREP * 64 + 16);   // epilogue staging tiles
     if (lds < epi) lds = epi;
     YAMD_REQUIRE(lds <= 160 * 1024, "conv tile needs %zu bytes of LDS", lds);

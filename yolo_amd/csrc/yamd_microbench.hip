@@ -26,10 +26,19 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(const bf16x8 *__restrict
     sink[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// four independent 16-byte loads in flight per lane before the first store
 __global__ __launch_bounds__(256) void stream_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
 {
     const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a;
+        dst[i + stride] = b;
+        dst[i + 2 * stride] = c;
+        dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 }  // namespace
@@ -47,7 +56,7 @@ extern "C" int yamd_microbench_copy(const void *src, void *dst, size_t bytes, vo
 {
     YAMD_REQUIRE(src && dst && bytes >= 16 && bytes % 16 == 0, "bad argument");
     YAMD_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "buffers must be 16-byte aligned");
-    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const uint4 *)src, (uint4 *)dst,
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const uint4 *)src, (uint4 *)dst,
                        bytes / 16);
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;

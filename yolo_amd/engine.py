@@ -113,6 +113,7 @@ class Program:
         self.convs: List[ConvLayer] = []
         self.stems: List[StemLayer] = []
         self.outputs: Dict[str, View] = {}
+        self.taps: Dict[str, View] = {}                 # named intermediate activations (verification aid, see read_view)
         self.alias: Dict[str, Tuple[str, int]] = {}     # buffer -> (wider buffer it lives in, first channel)
         self._alloc: Dict[Tuple[int, str], Dict[str, torch.Tensor]] = {}
         self._n = 0
@@ -364,6 +365,12 @@ class Program:
         return best
 
     # ---- accounting ------------------------------------------------------------------------------
+    def read_view(self, v: View, batch: int, device) -> torch.Tensor:
+        """The current contents of an activation view as a float32 NCHW tensor (after a ``run`` with this batch)."""
+        bufs = self._buffers_for(batch, device)
+        buf, coff = self.resolve(v)
+        return bufs[buf][..., coff:coff + v.c].permute(0, 3, 1, 2).float().contiguous()
+
     def n_conv_launches(self) -> int:
         return sum(1 for op in self.ops if op[0] in ("conv", "stem"))
 

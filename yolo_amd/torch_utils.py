@@ -140,15 +140,16 @@ def decode_anchor_levels(raws: List[torch.Tensor], anchors, strides, img_size: i
     C = raws[0].shape[-1] // na
     A = sum(na * r.shape[1] * r.shape[2] for r in raws)
     out = _out(arena, "decoded", (B, A, C), torch.float32, raws[0].device)
-    off = 0
-    st = _lib.current_stream()
-    for i, (r, s) in enumerate(zip(raws, strides)):
+    n = len(raws)
+    for r in raws:
         _lib.require_gpu(r, torch.float32, "raw head")
-        wh = (ctypes.c_float * (2 * na))(*[float(v) for a in anchors[i * na:(i + 1) * na] for v in a])
-        _lib.check(LIB.yamd_decode_anchor(kind, r.data_ptr(), B, r.shape[1], r.shape[2], na, C, wh, int(s), point_num,
-                                          float(img_size), 1, int(clamp_points), out.data_ptr(), A, off, st),
-                   "decode_anchor")
-        off += na * r.shape[1] * r.shape[2]
+    ptrs = (ctypes.c_void_p * n)(*[r.data_ptr() for r in raws])
+    hs = (ctypes.c_int * n)(*[r.shape[1] for r in raws])
+    ws = (ctypes.c_int * n)(*[r.shape[2] for r in raws])
+    ss = (ctypes.c_int * n)(*[int(s) for s in strides])
+    wh = (ctypes.c_float * (2 * na * n))(*[float(v) for a in anchors[:n * na] for v in a])
+    _lib.check(LIB.yamd_decode_anchor_levels(kind, ptrs, hs, ws, ss, wh, n, B, na, C, point_num, float(img_size),
+                                             int(clamp_points), out.data_ptr(), _lib.current_stream()), "decode_anchor_levels")
     return out
 
 

@@ -148,29 +148,32 @@ class YoloV5(AnchorTaskModel):
         cat_n4 = P.buffer(s16, s16, 2 * c3ch, name="cat_n4")          # [down(p3) | p4]
         cat_n5 = P.buffer(s32, s32, 2 * c4ch, name="cat_n5")          # [down(p4) | p5]
 
-        x = B.cbs("stem", bb.stem.conv, P.focus())
-        x = B.c3("dark2.1", bb.dark2[1], B.cbs("dark2.0", bb.dark2[0], x), True)
-        B.c3("dark3.1", bb.dark3[1], B.cbs("dark3.0", bb.dark3[0], x), True, out=cat_p3.slice(c3ch, c3ch))
-        feat1 = cat_p3.slice(c3ch, c3ch)
+        T = P.taps
+        T["stem"] = x = B.cbs("stem", bb.stem.conv, P.focus())
+        T["dark2.0"] = x = B.cbs("dark2.0", bb.dark2[0], x)
+        T["dark2"] = x = B.c3("dark2.1", bb.dark2[1], x, True)
+        T["dark3.0"] = d30 = B.cbs("dark3.0", bb.dark3[0], x)
+        B.c3("dark3.1", bb.dark3[1], d30, True, out=cat_p3.slice(c3ch, c3ch))
+        T["feat1"] = feat1 = cat_p3.slice(c3ch, c3ch)
         B.c3("dark4.1", bb.dark4[1], B.cbs("dark4.0", bb.dark4[0], feat1), True, out=cat_p4.slice(c4ch, c4ch))
-        feat2 = cat_p4.slice(c4ch, c4ch)
-        x = B.cbs("dark5.0", bb.dark5[0], feat2)
+        T["feat2"] = feat2 = cat_p4.slice(c4ch, c4ch)
+        T["dark5.0"] = x = B.cbs("dark5.0", bb.dark5[0], feat2)
         spp = bb.dark5[1]
         hc = spp.cv1.conv.out_channels
         cat_spp = P.buffer(s32, s32, 4 * hc, name="cat_spp")
         B.cbs("spp.cv1", spp.cv1, x, out=cat_spp.slice(0, hc))
         P.maxpool5_cascade(cat_spp.slice(0, hc), cat_spp.slice(hc, hc), cat_spp.slice(2 * hc, hc),
                            cat_spp.slice(3 * hc, hc))
-        x = B.cbs("spp.cv2", spp.cv2, cat_spp)
-        feat3 = B.c3("dark5.2", bb.dark5[2], x, False)
+        T["spp"] = x = B.cbs("spp.cv2", spp.cv2, cat_spp)
+        T["feat3"] = feat3 = B.c3("dark5.2", bb.dark5[2], x, False)
 
-        p5 = B.cbs("conv_for_feat3", body.conv_for_feat3, feat3, out=cat_n5.slice(c4ch, c4ch))
+        T["p5_lateral"] = p5 = B.cbs("conv_for_feat3", body.conv_for_feat3, feat3, out=cat_n5.slice(c4ch, c4ch))
         P.upsample2x(p5, cat_p4.slice(0, c4ch))
         p4 = B.c3("conv3_for_up_sample1", body.conv3_for_up_sample1, cat_p4, False)
         p4 = B.cbs("conv_for_feat2", body.conv_for_feat2, p4, out=cat_n4.slice(c3ch, c3ch))
         P.upsample2x(p4, cat_p3.slice(0, c3ch))
-        p3 = B.c3("conv3_for_up_sample2", body.conv3_for_up_sample2, cat_p3, False)
-        B.cbs("down_sample1", body.down_sample1, p3, out=cat_n4.slice(0, c3ch))
+        T["p3"] = p3 = B.c3("conv3_for_up_sample2", body.conv3_for_up_sample2, cat_p3, False)
+        T["down_sample1"] = B.cbs("down_sample1", body.down_sample1, p3, out=cat_n4.slice(0, c3ch))
         p4 = B.c3("conv3_for_down_sample1", body.conv3_for_down_sample1, cat_n4, False)
         B.cbs("down_sample2", body.down_sample2, p4, out=cat_n5.slice(0, c4ch))
         p5 = B.c3("conv3_for_down_sample2", body.conv3_for_down_sample2, cat_n5, False)
