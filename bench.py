@@ -319,6 +319,25 @@ def realistic_regime(args, p, model, images, sink, steps=5):
             "weights": "spread random init, objectness bias -5 (seed 0)"}
 
 
+def small_batch_latency(model, p, dev, batches=(1, 16), reps=20):
+    """Host-visible latency of ``predict`` (H2D of the images not included: they are resident; D2H of the detections
+    included) at small batch sizes: median over ``reps`` synchronous calls after 3 warm-ups."""
+    out = {}
+    for B in batches:
+        imgs = device_images(B, p.img_size, 10_000, dev)
+        for _ in range(3):
+            model.predict({"batch_images": imgs})
+        ts = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            model.predict({"batch_images": imgs})
+            ts.append(time.perf_counter() - t0)
+        ms = statistics.median(ts) * 1e3
+        out["batch%d" % B] = {"ms": round(ms, 3), "images_per_s": round(B / ms * 1e3, 1)}
+    return out
+
+
 def measured_peaks(dev):
     """The two denominators measured on this device, beside the nominal ones: a register-operand bf16 MFMA loop on
     random data (2 wavefronts per SIMD) and a 16-byte streaming copy of 1 GiB (read + write bytes)."""
@@ -346,10 +365,15 @@ def measured_peaks(dev):
     nbytes = 1 << 30
     src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 255)
     dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    ms2 = timed(lambda: L.check(L.LIB.yamd_microbench_copy(src.data_ptr(), dst.data_ptr(), nbytes, st)), 3, 9)
+    variants = {v: timed(lambda v=v: L.check(L.LIB.yamd_microbench_copy(src.data_ptr(), dst.data_ptr(), nbytes, v, st)), 3, 7)
+                for v in range(4)}
+    best = min(variants, key=variants.get)
     return {"mfma_bf16_TFLOPs": round(mfma, 1), "mfma_loop": "v_mfma_f32_32x32x16_bf16, register operands, random data, "
             "8 wavefronts per CU, %.2f ms per launch" % ms,
-            "hbm_copy_GBs": round(2.0 * nbytes / (ms2 * 1e-3) / 1e9, 1), "hbm_copy": "1 GiB float4 copy, read + write bytes"}
+            "hbm_copy_GBs": round(2.0 * nbytes / (variants[best] * 1e-3) / 1e9, 1),
+            "hbm_copy": "1 GiB copy with 16-byte accesses, read + write bytes, best of four variants (%s)" % ", ".join(
+                "%s%d in flight: %.0f GB/s" % ("non-temporal " if v >= 2 else "", 4 if v % 2 == 0 else 8,
+                                                2.0 * nbytes / (t * 1e-3) / 1e9) for v, t in variants.items())}
 
 
 def measured_conv_traffic(model_name: str, batch: int, n_conv: int):
@@ -516,6 +540,9 @@ def main():
             out["decode_hbm"]["frac_of_measured_copy"] = round(out["decode_hbm"]["achieved_GBs"] / peaks["hbm_copy_GBs"], 4)
             if args.model == "v5s" and world == 1:
                 out["nms_regime_realistic"] = realistic_regime(args, p, model, images, sink)
+            if world == 1:
+                del images, sink
+                out["latency_small_batch"] = small_batch_latency(model, p, dev)
         if args.detail:
             with open(args.detail, "w") as f:
                 for r in sorted(prof["table"], key=lambda r: -r["ms"]):

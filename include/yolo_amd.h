@@ -288,10 +288,12 @@ int yamd_stem_conv(int mode, const float *images, int batch, int h, int w, const
  *   yamd_microbench_mfma_bf16: `blocks` workgroups of 4 wavefronts, each wavefront issues 4*iters
  *       v_mfma_f32_32x32x16_bf16 (32768 FLOP each) on register operands taken from `operands` (4 KB of bf16, device);
  *       `sink` receives blocks*256 floats.  FLOP = blocks * 4 * 4 * iters * 32768.
- *   yamd_microbench_copy: dst[i] = src[i] with 16-byte accesses; bytes % 16 == 0.  Traffic = 2 * bytes.
+ *   yamd_microbench_copy: dst[i] = src[i] with 16-byte accesses, every workgroup on contiguous 16 KB pieces;
+ *       variant 0 / 1: 4 / 8 pieces in flight per lane, 2 / 3: the same with non-temporal accesses; bytes % 16 == 0.
+ *       Traffic = 2 * bytes.
  * ---------------------------------------------------------------------------------------- */
 int yamd_microbench_mfma_bf16(const void *operands, float *sink, int blocks, int iters, void *stream);
-int yamd_microbench_copy(const void *src, void *dst, size_t bytes, void *stream);
+int yamd_microbench_copy(const void *src, void *dst, size_t bytes, int variant, void *stream);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_W
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/scratch/run_program.py $model $batch 2 $O/ops.json > $O/pmc_fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/scratch/run_program.py $model $batch 2 $O/ops.json > $O/pmc_write.log 2>&1
 cd $R
-python3 scratch/layer_table.py $O > $O/layers.txt
+python3 scratch/layer_table.py $O $O/conv_hbm_traffic.json > $O/layers.txt
 head -5 $O/layers.txt; tail -4 $O/layers.txt
 # keep the merge small: the raw csv files are large
 rm -rf $O/trace $O/pmc_sq $O/pmc_fetch $O/pmc_write

@@ -65,5 +65,14 @@ for op, us, s, f, w in zip(ops, dur, sq, fe, wr):
             tot[k] += v
     print(f"{op['kind']:5s} {op['name'][:34]:34s} {us:8.1f} {op['flops'] / us / 1e6:7.1f} {mf:6.1f} {wait:6.1f} {ldsw:6.1f} {park:6.1f} {act:6.1f} {r:8.1f} {wv:8.1f} "
           f"{op['bytes'] / 1e6:8.1f} {(r + wv) / us * 1e3:7.0f}  {op['desc']}")
+n_conv = sum(1 for op in ops if op["kind"] in ("conv", "stem"))
+if len(sys.argv) > 2:
+    json.dump(dict(model=meta["model"], batch=meta["batch"], convs_per_pass=n_conv, read_bytes=tot["r"] * 1e6, write_bytes=tot["w"] * 1e6,
+                   bytes_per_launch=(tot["r"] + tot["w"]) * 1e6 / n_conv, conv_us=tot["us"], conv_flops=tot["fl"],
+                   mfma_busy_frac_at_2p4GHz=tot["busy"] / (tot["us"] * 1e-6 * 2.4e9 * 1024),
+                   note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate passes over the conv "
+                        "program of the benchmark configuration (scratch/layer_counters.sh); KB units; FETCH_SIZE doubled (gfx950 "
+                        "counts the 128-byte requests of wide coalesced loads as 64 bytes); durations from a --kernel-trace pass"),
+              open(sys.argv[2], "w"), indent=1)
 print(f"# conv launches: {tot['us'] / 1e3:.3f} ms, {tot['fl'] / tot['us'] / 1e6:.1f} TFLOP/s, MFMA busy {tot['busy'] / (tot['us'] * 1e-6 * 2.4e9 * 1024) * 100:.1f} %, "
       f"HBM read {tot['r'] / 1e3:.2f} GB + write {tot['w'] / 1e3:.2f} GB vs algorithmic {tot['alg'] / 1e3:.2f} GB")

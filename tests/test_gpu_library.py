@@ -92,6 +92,19 @@ def test_nms_300_classes(gpu_device):
     _check(rows, counts, want, index, want_idx)
 
 
+def test_nms_100800_anchors_per_image(gpu_device):
+    """The anchor count of a 1280 x 1280 YOLOv5 input (3 * (160^2 + 80^2 + 40^2)): more than 65536 anchors per image."""
+    from oracle import postprocess as pp
+    from oracle.gen_golden_synth import synthetic_pred
+    from yolo_amd import torch_utils as tu
+    pred = synthetic_pred(np.random.RandomState(17), 1, 100800, 5, 1280.0, clusters=300)
+    want, want_idx = pp.non_max_suppression(pred, 1280.0, "cxcywh", 0.25, 0.3, return_index=True)
+    assert want[0] is not None and want[0].shape[0] > 100
+    rows, counts, index = tu.nms_batched(torch.from_numpy(pred).to(gpu_device), 1280.0, "cxcywh", 0.25, 0.3, 0,
+                                         want_index=True)
+    _check(rows, counts, want, index, want_idx)
+
+
 def test_rejects_images_that_are_not_rgb(gpu_device):
     from yolo_amd import lib as L
     from yolo_amd.param import Yolo5Param

@@ -30,12 +30,13 @@ struct Level {
     float aw[4], ah[4];       // anchor / stride, fp32 division as torch does it (anchor heads)
 };
 
-// copies `total` floats from global to LDS, 16 bytes per lane where the source is aligned
+// copies `total` floats from global to LDS, 16 bytes per lane where the source is aligned.  The logits are read once
+// and the decoded rows written once: both go past the caches (non-temporal), which is worth ~5 % on a streaming copy.
 __device__ __forceinline__ void stage_rows(float *dst, const float *src, int total)
 {
     if (((uintptr_t)src & 15) == 0) {
         const int t4 = total >> 2;
-        for (int i = threadIdx.x; i < t4; i += 256) ((float4 *)dst)[i] = ((const float4 *)src)[i];
+        for (int i = threadIdx.x; i < t4; i += 256) ((f32x4 *)dst)[i] = __builtin_nontemporal_load((const f32x4 *)src + i);
         for (int i = (t4 << 2) + threadIdx.x; i < total; i += 256) dst[i] = src[i];
     } else {
         for (int i = threadIdx.x; i < total; i += 256) dst[i] = src[i];
@@ -49,9 +50,10 @@ __device__ __forceinline__ void store_run(float *dst, int n, F &&f)
     if (((uintptr_t)dst & 15) == 0) {
         const int n4 = n >> 2;
         for (int q = threadIdx.x; q < n4; q += 256) {
-            float4 v;
-            f(4 * q, v.x, v.y, v.z, v.w);
-            ((float4 *)dst)[q] = v;
+            float a, b, c, d;
+            f(4 * q, a, b, c, d);
+            const f32x4 v = {a, b, c, d};
+            __builtin_nontemporal_store(v, (f32x4 *)dst + q);
         }
         for (int e = (n4 << 2) + threadIdx.x; e < n; e += 256) {
             float a, b, c, d;
@@ -394,7 +396,6 @@ int decode_free_impl(const float *const *raws, const int *hs, const int *ws, con
     FreeDecodeParams p;
     const int CI = 4 * bins + 2 * point_num + ncs, CO = 5 + 2 * point_num + ncs;
     p.pix = pick_pix(CI + 5);
-    if (p.pix > 32) p.pix = 32;         // 128 box-side tasks fill the four-lane phase of a 256-thread workgroup twice
     const size_t lds = (size_t)p.pix * (CI + 5) * sizeof(float);
     YAMD_REQUIRE(lds <= 64 * 1024 && (long long)(p.pix * CO + 4) * CO < (1ll << 22), "bins/point_num/nc too large for the decode tile");
     long long rows = 0;
@@ -414,7 +415,7 @@ int decode_free_impl(const float *const *raws, const int *hs, const int *ws, con
     {
         const int nt = 2 * point_num + ncs;
         p.nchunk = 1;
-        while (p.nchunk < 16 && p.nchunk * p.pix < 512 && nt / (p.nchunk * 2) >= 2) p.nchunk *= 2;
+        while (p.nchunk < 16 && p.nchunk * p.pix < 768 && nt / (p.nchunk * 2) >= 2) p.nchunk *= 2;
         p.cw = (nt + p.nchunk - 1) / p.nchunk;
     }
     hipLaunchKernelGGL(decode_free_kernel, dim3(blocks, batch), dim3(256), lds, (hipStream_t)stream, p);

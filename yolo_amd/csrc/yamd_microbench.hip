@@ -26,19 +26,30 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(const bf16x8 *__restrict
     sink[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
-// four independent 16-byte loads in flight per lane before the first store
-__global__ __launch_bounds__(256) void stream_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+// Every workgroup copies contiguous 16 KB pieces (one 16-byte access per lane and piece, UNROLL pieces in flight per
+// lane before the first store); `mode` selects plain or non-temporal accesses.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void stream_copy_kernel(const u32x4 *__restrict__ src, u32x4 *__restrict__ dst, size_t n16)
 {
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a;
-        dst[i + stride] = b;
-        dst[i + 2 * stride] = c;
-        dst[i + 3 * stride] = d;
+    const size_t chunk = (size_t)256 * UNROLL;                    // 16-byte elements per workgroup step
+    for (size_t base = (size_t)blockIdx.x * chunk; base < n16; base += (size_t)gridDim.x * chunk) {
+        u32x4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const size_t i = base + (size_t)u * 256 + threadIdx.x;
+            if (i < n16) v[u] = NT ? __builtin_nontemporal_load(src + i) : src[i];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const size_t i = base + (size_t)u * 256 + threadIdx.x;
+            if (i < n16) {
+                if (NT) __builtin_nontemporal_store(v[u], dst + i);
+                else dst[i] = v[u];
+            }
+        }
     }
-    for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 }  // namespace
@@ -52,12 +63,18 @@ extern "C" int yamd_microbench_mfma_bf16(const void *operands, float *sink, int 
     return YAMD_OK;
 }
 
-extern "C" int yamd_microbench_copy(const void *src, void *dst, size_t bytes, void *stream)
+extern "C" int yamd_microbench_copy(const void *src, void *dst, size_t bytes, int variant, void *stream)
 {
     YAMD_REQUIRE(src && dst && bytes >= 16 && bytes % 16 == 0, "bad argument");
     YAMD_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0, "buffers must be 16-byte aligned");
-    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const uint4 *)src, (uint4 *)dst,
-                       bytes / 16);
+    YAMD_REQUIRE(variant >= 0 && variant < 4, "variant %d: 0 = 4 pieces in flight, 1 = 8, 2 / 3 = the same non-temporal", variant);
+    const size_t n16 = bytes / 16;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(256 * 16), block(256);
+    if (variant == 0) hipLaunchKernelGGL((stream_copy_kernel<4, false>), grid, block, 0, st, (const u32x4 *)src, (u32x4 *)dst, n16);
+    else if (variant == 1) hipLaunchKernelGGL((stream_copy_kernel<8, false>), grid, block, 0, st, (const u32x4 *)src, (u32x4 *)dst, n16);
+    else if (variant == 2) hipLaunchKernelGGL((stream_copy_kernel<4, true>), grid, block, 0, st, (const u32x4 *)src, (u32x4 *)dst, n16);
+    else hipLaunchKernelGGL((stream_copy_kernel<8, true>), grid, block, 0, st, (const u32x4 *)src, (u32x4 *)dst, n16);
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
 }

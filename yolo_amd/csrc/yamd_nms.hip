@@ -462,7 +462,7 @@ __global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
         for (u32 r = tid; r < n; r += SEG_THREADS) {
             const u32 c = posr[r];
             const u32 t = atomicAdd(&hist[c], 1u);
-            posr[r] = c | (t << 12);                    // ticket < n <= 65536
+            posr[r] = c | (t << 12);                    // cell < 4096, ticket < n <= 2^18
         }
         __syncthreads();
         scan_cells();
@@ -1011,7 +1011,9 @@ int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, 
     while (frows > 8 && (size_t)frows * (c | 1) * 4 + (size_t)nc * 8 + 16 > 150 * 1024) frows >>= 1;
     const size_t flds = (size_t)frows * (c | 1) * 4 + (size_t)nc * 8 + 16;
     YAMD_REQUIRE(flds <= 150 * 1024, "C=%d too wide for the filter tile", c);
-    YAMD_REQUIRE(a <= 65536, "A=%d exceeds the 65536 anchors per image supported", a);
+    // 20 bits of posr hold a candidate's ticket inside its grid cell, and the sweep keeps 28 bytes per group of 64
+    // candidates in LDS
+    YAMD_REQUIRE(a <= (1 << 18), "A=%d exceeds the 262144 anchors per image supported", a);
     int sort_cap = 8;
     while (sort_cap < a && sort_cap < 8192) sort_cap <<= 1;
     const size_t ngmax = (size_t)(a + 63) / 64;
@@ -1020,6 +1022,7 @@ int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, 
     size_t slds = sort_lds > sweep_lds ? sort_lds : sweep_lds;
     const size_t group_lds = (size_t)(CELLS + SEG_WAVES) * 4;
     if (slds < group_lds) slds = group_lds;
+    YAMD_REQUIRE(slds <= 160 * 1024, "A=%d needs %zu bytes of LDS for the sweep", a, slds);
     char *ws = (char *)workspace;
     NmsParams p;
     p.pred = pred;

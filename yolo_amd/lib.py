@@ -84,7 +84,7 @@ def _load() -> ctypes.CDLL:
     lib.yamd_stem_pack_weights.argtypes = [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.yamd_stem_conv.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]
     lib.yamd_microbench_mfma_bf16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
-    lib.yamd_microbench_copy.argtypes = [c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.yamd_microbench_copy.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_void_p]
     lib.yamd_letterbox_workspace_bytes.restype = c_size_t
     lib.yamd_letterbox_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.yamd_letterbox_u8.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
