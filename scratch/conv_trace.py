@@ -4,13 +4,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from yolo_amd import lib as L
 k, s, cin, cout, H, tw, mrep, nrep, ck = [int(v) for v in sys.argv[1:10]]
-B = 256
-so = os.path.join(ROOT, "scratch", f"libconv_trace_{k}{s}_{tw}_{mrep}{nrep}_{ck}.so")
+nw, stages, B = [int(v) for v in sys.argv[10:13]] if len(sys.argv) > 12 else (4, 1, 256)
+so = os.path.join(ROOT, "scratch", f"libconv_trace_{k}{s}_{tw}_{mrep}{nrep}_{ck}" + (f"_{nw}_{stages}" if (nw, stages) != (4, 1) else "") + ".so")
 lib = ctypes.CDLL(so)
 d = L.ConvDesc()
 L.check(L.LIB.yamd_conv_desc_init(ctypes.byref(d), k, s, cin, cout, 1, 0))
 if (d.mrep, d.nrep, d.ck) != (mrep, nrep, ck):
-    L.check(L.LIB.yamd_conv_desc_tune(ctypes.byref(d), mrep, nrep, ck, 4))
+    L.check(L.LIB.yamd_conv_desc_tune(ctypes.byref(d), min(mrep, 2), nrep, ck, 4, 1))
 w = torch.randn(cout, cin, k, k) * 0.05
 wp = torch.empty(d.packed_w_elems, dtype=torch.int16); bp = torch.empty(d.cout_pad)
 L.check(L.LIB.yamd_conv_pack_weights(ctypes.byref(d), w.data_ptr(), cin, torch.zeros(cout).data_ptr(), wp.data_ptr(), bp.data_ptr()))
@@ -35,4 +35,7 @@ for i, n in enumerate(names):
     print(f"  {n:12s} mean {d_[:, i].mean():9.0f}  median {np.median(d_[:, i]):9.0f}  p90 {np.percentile(d_[:, i], 90):9.0f}")
 print(f"  block total  mean {(t[:,4]-t[:,0]).mean():9.0f}")
 if t[:, 7].min() > 0:
-    print(f"  chunk 1: issue+MFMA {np.median(t[:,6]-t[:,5]):8.0f}   barrier+write+barrier {np.median(t[:,7]-t[:,6]):8.0f}")
+    if stages == 1:
+        print(f"  chunk 1: issue+MFMA {np.median(t[:,6]-t[:,5]):8.0f}   barrier+write+barrier {np.median(t[:,7]-t[:,6]):8.0f}")
+    else:
+        print(f"  chunk 1 (pipelined): {np.median(t[:,7]-t[:,5]):8.0f}   first chunk's loads landed after {np.median(t[:,6]-t[:,1]):8.0f}")

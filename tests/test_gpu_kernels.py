@@ -253,6 +253,11 @@ def test_conv_tilings(gpu_device, k, s, cin, cout, H, W, use_res, tiling):
     (3, 2, 64, 128, 40, 40, False, (2, 4, 16, 4, 1)),     # stride 2: two zero rows between the stacked images
     (3, 2, 64, 128, 38, 38, False, (1, 4, 16, 4, 1)),
     (3, 2, 32, 64, 12, 20, False, (1, 2, 16, 8, 1)),
+    # two LDS images: one workgroup walks the three cout tiles (the last one partly filled) of its pixel tile
+    (3, 1, 80, 320, 19, 19, True, (2, 4, 16, 8, 2)),
+    (3, 1, 48, 296, 26, 22, False, (2, 4, 16, 4, 2)),
+    (1, 1, 96, 328, 20, 20, True, (2, 4, 32, 8, 2)),
+    (3, 2, 48, 200, 38, 38, False, (1, 4, 16, 4, 2)),
 ])
 def test_conv_small_maps_stacked_images(gpu_device, k, s, cin, cout, H, W, use_res, tiling):
     """Small feature maps: the launcher tiles the whole batch as one tall image (zero rows between the images), so

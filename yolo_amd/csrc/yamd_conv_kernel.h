@@ -55,6 +55,9 @@ struct ConvParams {
 #ifdef YAMD_CONV_TRACE
     unsigned long long *trace;   // 8 timestamps per workgroup (profiling builds only)
 #endif
+#ifdef YAMD_CONV_SKEW
+    int skew, skew_blocks;       // experiment: workgroups of the first round that are not first on their SIMD start `skew` cycles late
+#endif
 };
 
 #ifdef YAMD_CONV_TRACE
@@ -122,8 +125,9 @@ __device__ __forceinline__ void act4(float (&v)[4])
 }
 
 // STAGES = 1: one LDS image of the current chunk; the next chunk waits in registers and is written between two
-// barriers.  STAGES = 2: two LDS images; the next chunk is written into the other image while the current one is
-// being read, so a chunk costs one barrier and the LDS writes overlap the other waves' MFMAs.
+// barriers; a workgroup computes one cout tile of one pixel tile.  STAGES = 2: two LDS images and a software pipeline:
+// the staging (LDS stores of the next chunk, global loads of the one after) is spread between the MFMAs of the current
+// chunk, a chunk costs one barrier, and a workgroup computes all cout tiles of its pixel tile in one stream.
 template <int KS, int S, int TW, int MREP, int NREP, int CK, bool OUT_F32, int ACTK, int NW, int STAGES = 1>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void conv_igemm_kernel(ConvParams p)
 {
@@ -148,9 +152,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
     const int per_xcd = gridDim.x >> 3;
     int bid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (bid >= p.total_tiles) return;
+#ifdef YAMD_CONV_SKEW
+    if ((int)blockIdx.x < p.skew_blocks) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u;   // HW_ID.wave_id: this wave's slot on its SIMD
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        const unsigned long long wait = (unsigned long long)p.skew * slot;
+        while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     YAMD_STAMP(0);
-    const int nt = bid % p.n_tiles;
-    bid /= p.n_tiles;
+    // one image: a workgroup owns one cout tile of one pixel tile.  Two images: it owns the pixel tile and walks its
+    // cout tiles one after the other (the chunk stream simply continues into the next cout tile's weights)
+    const int nt0 = STAGES == 2 ? 0 : bid % p.n_tiles;
+    if constexpr (STAGES != 2) bid /= p.n_tiles;
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
@@ -223,7 +237,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
         inb_mask |= inb ? (1u << u) : 0u;
     });
     const __bf16 *ximg = p.x + (size_t)b * p.H * p.W * p.x_cs;
-    const char *wtile = p.w + (size_t)nt * p.nchunks * WBYTES;
+    const char *wtile = p.w + (size_t)nt0 * p.nchunks * WBYTES;
     auto issue_loads = [&](int ch) __attribute__((always_inline)) {
         const char *wsrc = wtile + (size_t)ch * WBYTES;
         static_for<WP>([&](auto uc) __attribute__((always_inline)) {
@@ -234,11 +248,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
         const __bf16 *xc = ximg + ch * CK;
         static_for<AP>([&](auto uc) __attribute__((always_inline)) {
             constexpr int u = decltype(uc)::value;
-            const u32x4 v = *(const u32x4 *)(xc + goff[u]);
-            ra[u] = ((inb_mask >> u) & 1u) ? v : u32x4{0u, 0u, 0u, 0u};
+            ra[u] = *(const u32x4 *)(xc + goff[u]);
         });
     };
-    const int stage_bytes = WBYTES + Lds::image_bytes(NPH);   // one LDS image: weights, then the halo tile (multiple of 16)
+    // one LDS image: weights, then the halo tile (multiple of 16).  With two images the epilogue of a cout tile runs
+    // in the image that the next chunk does not read, so an image is at least as large as the epilogue tiles.
+    constexpr int EPI_BYTES = NW * 32 * (OUT_F32 ? NREP * 128 + 16 : NREP * 64 + 16);
+    const int stage_bytes = STAGES == 2 ? max(WBYTES + Lds::image_bytes(NPH), EPI_BYTES) : WBYTES + Lds::image_bytes(NPH);
     auto write_lds = [&](int stage) __attribute__((always_inline)) {
         char *ldsW = smem + stage * stage_bytes;
         char *ldsA = ldsW + WBYTES;
@@ -249,270 +265,385 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
         });
         static_for<AP>([&](auto uc) __attribute__((always_inline)) {
             constexpr int u = decltype(uc)::value;
-            *(u32x4 *)(ldsA + loff[u]) = ra[u];
+            // out-of-image pieces were loaded from a clamped address; they become zeros here, after the chunk's MFMAs,
+            // and not where the load is issued: a select placed there makes the wave wait for the load before it computes
+            *(u32x4 *)(ldsA + loff[u]) = ((inb_mask >> u) & 1u) ? ra[u] : u32x4{0u, 0u, 0u, 0u};
         });
     };
 
     YAMD_STAMP(1);
     issue_loads(0);
-    // (the first chunk is in flight while this runs) accumulators start at the bias: register 4i+j of fragment n is cout n*32 + 8i + 4g + j
+    // accumulators start at the bias: register 4i+j of fragment n is cout n*32 + 8i + 4g + j
     f32x16 acc[MREP][NREP];
+    auto init_acc = [&](int nt) __attribute__((always_inline)) {
 #pragma unroll
-    for (int n = 0; n < NREP; ++n)
+        for (int n = 0; n < NREP; ++n)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 bv = *(const f32x4 *)(p.bias + nt * (NREP * 32) + n * 32 + 8 * i + 4 * g);
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 bv = *(const f32x4 *)(p.bias + nt * (NREP * 32) + n * 32 + 8 * i + 4 * g);
 #pragma unroll
-            for (int m = 0; m < MREP; ++m)
+                for (int m = 0; m < MREP; ++m)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[m][n][4 * i + j] = bv[j];
-        }
+                    for (int j = 0; j < 4; ++j) acc[m][n][4 * i + j] = bv[j];
+            }
+    };
+    init_acc(nt0);      // (the first chunk is in flight while this runs)
 
-    write_lds(0);
-    __syncthreads();
-    YAMD_STAMP(2);
-    for (int ch = 0; ch < p.nchunks; ++ch) {
-        const bool more = ch + 1 < p.nchunks;
 #ifdef YAMD_CONV_TRACE
-        if (ch == 1) YAMD_STAMP(5);
+    if constexpr (STAGES == 2) {            // where the first stage spends its time: the first chunk's loads, or the rest
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        YAMD_STAMP(6);
+    }
 #endif
-        if (more) issue_loads(ch + 1);
-        const char *ldsW = smem + (STAGES == 2 ? (ch & 1) * stage_bytes : 0);
+    write_lds(0);
+    // One chunk's MFMAs on the LDS image at byte offset `img`.  A slot is one k-step of one tap.  With two LDS images
+    // the fragments of slot s+1 are read before the MFMAs of slot s are issued, staging(s) puts a share of the staging
+    // between them, and a scheduling barrier after every slot keeps that order in the generated code.
+    auto compute_chunk = [&](int img, auto staging) __attribute__((always_inline)) {
+        const char *ldsW = smem + img;
         const char *ldsA = ldsW + WBYTES;
         // compact image: the per-tap half selects are re-derived from one register in every chunk; hoisted out of the
         // loop they would occupy one address register per (fragment, tap)
         unsigned hs = halfsel;
         if constexpr (COMPACT) asm volatile("" : "+v"(hs));
+        auto read_frags = [&](auto sc, bf16x8(&a)[MREP], bf16x8(&wv)[NREP]) __attribute__((always_inline)) {
+            constexpr int slot = decltype(sc)::value;
+            constexpr int tap = slot / KSTEPS, ks = slot % KSTEPS;
+            constexpr int kh = tap / KS, kw = tap % KS;
+            constexpr int tapoff = (S == 1) ? (kh * NPW + kw) * RS : (kh * NPW + (kw & 1) * NPWH + (kw >> 1)) * RS;
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int kh = tap / KS, kw = tap % KS;
-            const int tapoff = (S == 1) ? (kh * NPW + kw) * RS : (kh * NPW + (kw & 1) * NPWH + (kw >> 1)) * RS;
-#pragma unroll
-            for (int ks = 0; ks < KSTEPS; ++ks) {
-                bf16x8 a[MREP], wv[NREP];
-#pragma unroll
-                for (int m = 0; m < MREP; ++m) {
-                    if constexpr (COMPACT) {
-                        const int tapc = (kh * CROW + (kw & 1) * NPWH + (kw >> 1)) * 32;
-                        a[m] = *(const bf16x8 *)(ldsA + pixoff[m] + tapc + (((hs >> (m * TAPS + tap)) & 1u) << 4));
-                    } else {
-                        a[m] = *(const bf16x8 *)(ldsA + pixoff[m] + tapoff + ks * 32);
-                    }
+            for (int m = 0; m < MREP; ++m) {
+                if constexpr (COMPACT) {
+                    constexpr int tapc = (kh * CROW + (kw & 1) * NPWH + (kw >> 1)) * 32;
+                    a[m] = *(const bf16x8 *)(ldsA + pixoff[m] + tapc + (((hs >> (m * TAPS + tap)) & 1u) << 4));
+                } else {
+                    a[m] = *(const bf16x8 *)(ldsA + pixoff[m] + tapoff + ks * 32);
                 }
+            }
+#pragma unroll
+            for (int n = 0; n < NREP; ++n)
+                wv[n] = *(const bf16x8 *)(ldsW + ((tap * KSTEPS + ks) * NREP + n) * 1024 + lane * 16);
+        };
+        constexpr int NBUF = STAGES == 2 ? 2 : 1;
+        bf16x8 a[NBUF][MREP], wv[NBUF][NREP];
+        if constexpr (NBUF == 2) read_frags(std::integral_constant<int, 0>{}, a[0], wv[0]);
+        static_for<TAPS * KSTEPS>([&](auto sc) __attribute__((always_inline)) {
+            constexpr int slot = decltype(sc)::value;
+            constexpr int cb = NBUF == 2 ? (slot & 1) : 0;
+            if constexpr (NBUF == 1) read_frags(sc, a[0], wv[0]);
+            else if constexpr (slot + 1 < TAPS * KSTEPS)
+                read_frags(std::integral_constant<int, slot + 1>{}, a[cb ^ 1], wv[cb ^ 1]);
+            staging(sc);
+#pragma unroll
+            for (int m = 0; m < MREP; ++m)
 #pragma unroll
                 for (int n = 0; n < NREP; ++n)
-                    wv[n] = *(const bf16x8 *)(ldsW + ((tap * KSTEPS + ks) * NREP + n) * 1024 + lane * 16);
-#pragma unroll
-                for (int m = 0; m < MREP; ++m)
-#pragma unroll
+#if defined(YAMD_CONV_ABLATE) && YAMD_CONV_ABLATE == 2
+                    asm volatile("" ::"v"(wv[cb][n]), "v"(a[cb][m]));      // profiling build without the MFMAs
+#else
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[cb][n], a[cb][m], acc[m][n], 0, 0, 0);
+#endif
+            if constexpr (NBUF == 2) __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // Epilogue of cout tile `nt`, staged through per-wave LDS tiles at `epi_lds` (a region no wave reads or stages into
+    // until the next barrier).
+    auto finish_tile = [&](const int nt, char *const epi_lds) __attribute__((always_inline)) {
+        // epilogue: lane holds, for pixel c32 of each fragment, couts 8*i + 4*g + j (i,j = 0..3)
+        if constexpr (OUT_F32) {
+            // float logits also go through a per-wave LDS tile [32 pixels][BN couts]: the global stores then walk the
+            // channels of one pixel (Cout*4 contiguous bytes) with consecutive lanes instead of one pixel per lane
+            constexpr int RSF = NREP * 128 + 16;       // bytes per pixel row of the staging tile
+            char *wreg = epi_lds + wave * (32 * RSF);
+    #pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+    #pragma unroll
+                for (int n = 0; n < NREP; ++n) {
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int cl = n * 32 + 8 * i + 4 * g;
+                        f32x4 v;
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = apply_act(acc[m][n][4 * i + j], p.act);
+                        *(f32x4 *)(wreg + c32 * RSF + cl * 4) = v;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int nco = min(NREP * 32, p.Cout - nt * (NREP * 32));
+                if (p.n_tiles == 1 && p.y_cs == p.Cout) {
+                    // pixels are dense in memory (one cout tile, no channel slice): walk the 32 x Cout values of the
+                    // fragment as one flat run, so every store instruction writes 256 contiguous bytes across pixel
+                    // boundaries (neighbouring pixels of a tile row are neighbours in memory)
+                    const float inv = 1.0f / (float)nco;
+                    const int total = 32 * nco;
+                    // Tile rows start at multiples of 4 pixels (TW and the fragment size are multiples of 4), so when the
+                    // image width is one too, every aligned group of 4 floats of the run lies inside one run of 4 pixels
+                    // that are neighbours in memory and all inside or all outside the image: 16-byte stores.
+                    if ((p.Wout & 3) == 0 && ((uintptr_t)p.y & 15) == 0) {
+                        for (int i = lane * 4; i < total; i += 256) {
+                            f32x4 v;
+                            int r0 = 0, c0 = 0;
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int r = (int)(((float)(i + j) + 0.5f) * inv);
+                                const int c = i + j - r * nco;
+                                if (j == 0) { r0 = r; c0 = c; }
+                                v[j] = *(const float *)(wreg + r * RSF + c * 4);
+                            }
+                            const int pq = wave * (32 * MREP) + m * 32 + r0;
+                            const int qr = pq / TW, qc = pq % TW;
+                            if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)
+                                *(f32x4 *)((float *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + c0) = v;
+                        }
+                    } else
+                    for (int i = lane; i < total; i += 64) {
+                        const int r = (int)(((float)i + 0.5f) * inv);
+                        const int c = i - r * nco;
+                        const int pq = wave * (32 * MREP) + m * 32 + r;
+                        const int qr = pq / TW, qc = pq % TW;
+                        if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)
+                            ((float *)p.y)[((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + c] =
+                                *(const float *)(wreg + r * RSF + c * 4);
+                    }
+                } else if ((nco & 3) == 0 && (p.y_cs & 3) == 0 && ((uintptr_t)p.y & 15) == 0) {
+                    // a channel slice of a wider pixel whose pieces are 16-byte aligned: every lane stores four channels
+                    // of one pixel, consecutive lanes walk the channels of a pixel, then the next pixel
+                    const int ppr = nco >> 2;
+                    const float invp = 1.0f / (float)ppr;
+                    for (int i = lane; i < 32 * ppr; i += 64) {
+                        const int r = (int)(((float)i + 0.5f) * invp);
+                        const int piece = i - r * ppr;
+                        const int pq = wave * (32 * MREP) + m * 32 + r;
+                        const int qr = pq / TW, qc = pq % TW;
+                        if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)
+                            *(f32x4 *)((float *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs +
+                                       nt * (NREP * 32) + piece * 4) = *(const f32x4 *)(wreg + r * RSF + piece * 16);
+                    }
+                } else {
+                    for (int r = 0; r < 32; ++r) {
+                        const int pq = wave * (32 * MREP) + m * 32 + r;
+                        const int qr = pq / TW, qc = pq % TW;
+                        if (!(qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)) continue;      // uniform in the wave
+                        float *y = (float *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + nt * (NREP * 32);
+    #pragma unroll
+                        for (int c = lane; c < NREP * 32; c += 64)
+                            if (c < nco) y[c] = *(const float *)(wreg + r * RSF + c * 4);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            // bf16 output goes through a per-wave LDS tile [32 pixels][BN couts] so that the global stores are
+            // 16 bytes per lane and whole pixel rows (BN*2 contiguous bytes) per group of lanes.
+            constexpr int RSO = NREP * 64 + 16;        // bytes per pixel row of the staging tile: the couts, then the pixel's output index
+            constexpr int PPR = NREP * 4;              // 16-byte pieces per pixel
+            constexpr int PIXPI = 64 / PPR;            // pixels per wave store instruction
+            char *wreg = epi_lds + wave * (32 * RSO);
+            // Everything that depends only on the lane or on the pixel is computed here, once: the output pixel index of
+            // this lane's pixel in every fragment (-1 = not stored) and, for the store loop, the lane's cout piece with its
+            // destination tensor.  The loops below then hold no index arithmetic.
+            int opixm[MREP];
+    #pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                const int pp = wave * (32 * MREP) + m * 32 + c32;
+                const int pr = pp / TW, pc = pp % TW;
+                int orow = oh0 + pr, obase = b * p.Hout;      // output row inside its image, first output row of the image
+                bool valid = pr < p.TH && ow0 + pc < p.Wout;
+                if (p.vout > 0) {
+                    const int vb = orow / p.vout;
+                    orow -= vb * p.vout;
+                    valid = valid && vb < p.vbatch;
+                    obase = vb * p.Hout;
+                }
+                valid = valid && orow < p.Hout;
+                opixm[m] = valid ? (obase + orow) * p.Wout + ow0 + pc : -1;
+            }
+            const int piece = lane % PPR, prow = lane / PPR;
+            const int sco = nt * (NREP * 32) + piece * 8;
+            const bool to_y = sco < p.split;
+            __bf16 *const sdst = to_y ? (__bf16 *)p.y + sco : p.y2 + (sco - p.split);
+            const size_t scs = to_y ? p.y_cs : p.y2_cs;
+            const bool sco_ok = sco < p.Cout;
+            const __bf16 *const resp = p.res;
+            const size_t res_cs = p.res_cs;
+            const float res_scale = p.res_scale;
+            const int cout_all = p.Cout;
+            auto epilogue = [&](auto mc, auto ac) __attribute__((always_inline)) {
+                constexpr int m = decltype(mc)::value;
+                constexpr int ACT = decltype(ac)::value;
+                const int opix = opixm[m];
+                // residual: all loads of this fragment are issued up front (clamped address instead of a divergent
+                // branch), so the epilogue pays one memory latency, not one per register quad
+                const bool has_res = resp != nullptr;      // uniform
+                bf16x4 rr[NREP][4];
+                if (has_res) {
+    #pragma unroll
                     for (int n = 0; n < NREP; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv[n], a[m], acc[m][n], 0, 0, 0);
+    #pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int co = nt * (NREP * 32) + n * 32 + 8 * i + 4 * g;
+                            const bool ok = opix >= 0 && co < cout_all;
+                            rr[n][i] = *(const bf16x4 *)(resp + (ok ? (size_t)opix * res_cs + co : (size_t)0));
+                        }
+                }
+                *(int *)(wreg + c32 * RSO + NREP * 64) = opix;      // both lanes of a pixel store the same value
+    #pragma unroll
+                for (int n = 0; n < NREP; ++n) {
+    #pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int cl = n * 32 + 8 * i + 4 * g;
+                        float v[4];
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = acc[m][n][4 * i + j];
+                        act4<ACT>(v);
+                        if (has_res) {
+    #pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += res_scale * (float)rr[n][i][j];
+                        }
+                        bf16x4 o;
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
+                        *(bf16x4 *)(wreg + c32 * RSO + cl * 2) = o;
+                    }
+                }
+                // the tile is private to this wave: order the LDS writes before the cross-lane reads
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+    #pragma unroll
+                for (int it = 0; it < 32 / PIXPI; ++it) {
+                    const char *row = wreg + (it * PIXPI + prow) * RSO;
+                    const uint4 v = *(const uint4 *)(row + piece * 16);
+                    const int spix = *(const int *)(row + NREP * 64);
+                    if (spix >= 0 && sco_ok) *(uint4 *)(sdst + (size_t)spix * scs) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            };
+            // ACTK >= 0: the activation is a compile-time constant of this kernel (small code); ACTK < 0: one
+            // uniform branch on the activation kind for the whole epilogue
+            auto run = [&](auto ac) __attribute__((always_inline)) {
+                static_for<MREP>([&](auto mc) __attribute__((always_inline)) { epilogue(mc, ac); });
+            };
+            if constexpr (ACTK >= 0) {
+                run(std::integral_constant<int, ACTK>{});
+            } else {
+                switch (p.act) {
+                case YAMD_ACT_LEAKY: run(std::integral_constant<int, YAMD_ACT_LEAKY>{}); break;
+                case YAMD_ACT_MISH: run(std::integral_constant<int, YAMD_ACT_MISH>{}); break;
+                case YAMD_ACT_RELU: run(std::integral_constant<int, YAMD_ACT_RELU>{}); break;
+                case YAMD_ACT_SILU: run(std::integral_constant<int, YAMD_ACT_SILU>{}); break;
+                default: run(std::integral_constant<int, YAMD_ACT_NONE>{}); break;
+                }
             }
         }
+    };
+
+    if constexpr (STAGES == 2) {
+        // Two LDS images, one barrier per chunk, and the staging spread over the chunk's MFMAs.  While chunk ch is
+        // computed from image ch&1, the registers hold chunk ch+1 (loaded during chunk ch-1): after every k-step a few
+        // of those pieces are stored into the other image and their registers are at once reloaded with chunk ch+2.
+        // A wave therefore never has a phase that only stores; waves that share a SIMD run in lockstep (same code, same
+        // barriers), so such a phase of one is not filled by the MFMAs of another.
+        // The last chunks reload the final chunk again and store pieces nobody reads: no branch inside the pipeline.
+        // The stream runs on through all cout tiles of the pixel tile (their weights follow each other in memory and
+        // the activations start over), so only the first chunk of the first cout tile is loaded with nothing to hide
+        // behind.  The very last chunks reload the final chunk again and store pieces nobody reads: no branch inside
+        // the pipeline.
+        constexpr int NSLOT = TAPS * KSTEPS, NPIECE = WP + AP;
+        const int last = p.n_tiles * p.nchunks - 1;      // index of the final chunk of the stream
+        {
+            const int l1 = min(1, last), c1 = l1 % p.nchunks;
+            const char *wsrc = p.w + (size_t)l1 * WBYTES;
+            const __bf16 *xc = ximg + c1 * CK;
+            static_for<WP>([&](auto uc) __attribute__((always_inline)) {
+                constexpr int u = decltype(uc)::value;
+                rw[u] = *(const u32x4 *)(wsrc + min(tid + u * NT, WBYTES / 16 - 1) * 16);
+            });
+            static_for<AP>([&](auto uc) __attribute__((always_inline)) {
+                constexpr int u = decltype(uc)::value;
+                ra[u] = *(const u32x4 *)(xc + goff[u]);
+            });
+        }
+        int lnext = min(2, last), cnext = lnext % p.nchunks;      // the chunk the next loads fetch, and its index inside its cout tile
+        int gi = 0;                                               // chunks computed so far
+        __syncthreads();
+        YAMD_STAMP(2);
+        for (int nt = 0; nt < p.n_tiles; ++nt) {
+            if (nt > 0) init_acc(nt);
+            for (int ch = 0; ch < p.nchunks; ++ch, ++gi) {
 #ifdef YAMD_CONV_TRACE
-        if (ch == 1) YAMD_STAMP(6);
+                if (gi == 1) YAMD_STAMP(5);
+                if (gi == 2) YAMD_STAMP(7);
 #endif
-        if constexpr (STAGES == 2) {
-            // the other image was last read one iteration ago, and every wave has passed that iteration's barrier
-            if (more) write_lds((ch + 1) & 1);
+                const int cur = (gi & 1) * stage_bytes;
+                char *nxtW = smem + (stage_bytes - cur);
+                char *nxtA = nxtW + WBYTES;
+                const char *wsrc = p.w + (size_t)lnext * WBYTES;
+                const __bf16 *xc = ximg + cnext * CK;
+                compute_chunk(cur, [&](auto sc) __attribute__((always_inline)) {
+                    constexpr int slot = decltype(sc)::value;
+                    constexpr int u0 = slot * NPIECE / NSLOT, u1 = (slot + 1) * NPIECE / NSLOT;
+                    static_for<u1 - u0>([&](auto uc) __attribute__((always_inline)) {
+                        constexpr int u = u0 + decltype(uc)::value;
+                        if constexpr (u < WP) {
+                            const int q = min(tid + u * NT, WBYTES / 16 - 1);
+                            *(u32x4 *)(nxtW + q * 16) = rw[u];
+                            rw[u] = *(const u32x4 *)(wsrc + q * 16);
+                        } else {
+                            constexpr int v = u - WP;
+                            *(u32x4 *)(nxtA + loff[v]) = ((inb_mask >> v) & 1u) ? ra[v] : u32x4{0u, 0u, 0u, 0u};
+                            ra[v] = *(const u32x4 *)(xc + goff[v]);
+                        }
+                    });
+                });
+                __syncthreads();   // every wave has read image `cur` and has stored its share of the other image
+                if (lnext < last) {
+                    ++lnext;
+                    if (++cnext == p.nchunks) cnext = 0;
+                }
+            }
+            // the image just computed from is free; the other one already holds the next cout tile's first chunk
+            finish_tile(nt, smem + ((gi & 1) ^ 1) * stage_bytes);
+            if (nt + 1 < p.n_tiles) __syncthreads();   // the next chunk stages into the image the epilogue used
+        }
+    } else {
+        __syncthreads();
+        YAMD_STAMP(2);
+        for (int ch = 0; ch < p.nchunks; ++ch) {
+            const bool more = ch + 1 < p.nchunks;
+#ifdef YAMD_CONV_TRACE
+            if (ch == 1) YAMD_STAMP(5);
+#endif
+#if !defined(YAMD_CONV_ABLATE) || YAMD_CONV_ABLATE == 2
+            if (more) issue_loads(ch + 1);
+#endif
+            compute_chunk(0, [](auto) __attribute__((always_inline)) {});
+#ifdef YAMD_CONV_TRACE
+            if (ch == 1) YAMD_STAMP(6);
+#endif
+#if defined(YAMD_CONV_ABLATE) && YAMD_CONV_ABLATE == 3
+            // profiling build: no staging and no barriers, the chunk loop re-reads the first chunk
+#elif defined(YAMD_CONV_ABLATE) && YAMD_CONV_ABLATE == 1
+            __syncthreads();   // profiling build: barriers kept, nothing staged
             __syncthreads();
-        } else {
+#else
             __syncthreads();   // every wave is done reading this chunk
             if (more) {
                 write_lds(0);
                 __syncthreads();
             }
-        }
-#ifdef YAMD_CONV_TRACE
-        if (ch == 1) YAMD_STAMP(7);
 #endif
+#ifdef YAMD_CONV_TRACE
+            if (ch == 1) YAMD_STAMP(7);
+#endif
+        }
+        YAMD_STAMP(3);
+        finish_tile(nt0, smem);      // the chunk loop ended with a barrier: LDS is free
     }
 
-    YAMD_STAMP(3);
-    // epilogue: lane holds, for pixel c32 of each fragment, couts 8*i + 4*g + j (i,j = 0..3)
-    if constexpr (OUT_F32) {
-        // float logits also go through a per-wave LDS tile [32 pixels][BN couts]: the global stores then walk the
-        // channels of one pixel (Cout*4 contiguous bytes) with consecutive lanes instead of one pixel per lane
-        constexpr int RSF = NREP * 128 + 16;       // bytes per pixel row of the staging tile
-        char *wreg = smem + wave * (32 * RSF);     // the chunk loop ended with a barrier: LDS is free
-#pragma unroll
-        for (int m = 0; m < MREP; ++m) {
-#pragma unroll
-            for (int n = 0; n < NREP; ++n) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int cl = n * 32 + 8 * i + 4 * g;
-                    f32x4 v;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = apply_act(acc[m][n][4 * i + j], p.act);
-                    *(f32x4 *)(wreg + c32 * RSF + cl * 4) = v;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            const int nco = min(NREP * 32, p.Cout - nt * (NREP * 32));
-            if (p.n_tiles == 1 && p.y_cs == p.Cout) {
-                // pixels are dense in memory (one cout tile, no channel slice): walk the 32 x Cout values of the
-                // fragment as one flat run, so every store instruction writes 256 contiguous bytes across pixel
-                // boundaries (neighbouring pixels of a tile row are neighbours in memory)
-                const float inv = 1.0f / (float)nco;
-                const int total = 32 * nco;
-                // Tile rows start at multiples of 4 pixels (TW and the fragment size are multiples of 4), so when the
-                // image width is one too, every aligned group of 4 floats of the run lies inside one run of 4 pixels
-                // that are neighbours in memory and all inside or all outside the image: 16-byte stores.
-                if ((p.Wout & 3) == 0 && ((uintptr_t)p.y & 15) == 0) {
-                    for (int i = lane * 4; i < total; i += 256) {
-                        f32x4 v;
-                        int r0 = 0, c0 = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int r = (int)(((float)(i + j) + 0.5f) * inv);
-                            const int c = i + j - r * nco;
-                            if (j == 0) { r0 = r; c0 = c; }
-                            v[j] = *(const float *)(wreg + r * RSF + c * 4);
-                        }
-                        const int pq = wave * (32 * MREP) + m * 32 + r0;
-                        const int qr = pq / TW, qc = pq % TW;
-                        if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)
-                            *(f32x4 *)((float *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + c0) = v;
-                    }
-                } else
-                for (int i = lane; i < total; i += 64) {
-                    const int r = (int)(((float)i + 0.5f) * inv);
-                    const int c = i - r * nco;
-                    const int pq = wave * (32 * MREP) + m * 32 + r;
-                    const int qr = pq / TW, qc = pq % TW;
-                    if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)
-                        ((float *)p.y)[((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + c] =
-                            *(const float *)(wreg + r * RSF + c * 4);
-                }
-            } else if ((nco & 3) == 0 && (p.y_cs & 3) == 0 && ((uintptr_t)p.y & 15) == 0) {
-                // a channel slice of a wider pixel whose pieces are 16-byte aligned: every lane stores four channels
-                // of one pixel, consecutive lanes walk the channels of a pixel, then the next pixel
-                const int ppr = nco >> 2;
-                const float invp = 1.0f / (float)ppr;
-                for (int i = lane; i < 32 * ppr; i += 64) {
-                    const int r = (int)(((float)i + 0.5f) * invp);
-                    const int piece = i - r * ppr;
-                    const int pq = wave * (32 * MREP) + m * 32 + r;
-                    const int qr = pq / TW, qc = pq % TW;
-                    if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)
-                        *(f32x4 *)((float *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs +
-                                   nt * (NREP * 32) + piece * 4) = *(const f32x4 *)(wreg + r * RSF + piece * 16);
-                }
-            } else {
-                for (int r = 0; r < 32; ++r) {
-                    const int pq = wave * (32 * MREP) + m * 32 + r;
-                    const int qr = pq / TW, qc = pq % TW;
-                    if (!(qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)) continue;      // uniform in the wave
-                    float *y = (float *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + nt * (NREP * 32);
-#pragma unroll
-                    for (int c = lane; c < NREP * 32; c += 64)
-                        if (c < nco) y[c] = *(const float *)(wreg + r * RSF + c * 4);
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-        }
-    } else {
-        // bf16 output goes through a per-wave LDS tile [32 pixels][BN couts] so that the global stores are
-        // 16 bytes per lane and whole pixel rows (BN*2 contiguous bytes) per group of lanes.
-        constexpr int RSO = NREP * 64 + 16;        // bytes per pixel row of the staging tile
-        constexpr int PPR = NREP * 4;              // 16-byte pieces per pixel
-        constexpr int PIXPI = 64 / PPR;            // pixels per wave store instruction
-        char *wreg = smem + wave * (32 * RSO);     // the chunk loop ended with a barrier: LDS is free
-        auto epilogue = [&](auto mc, auto ac) __attribute__((always_inline)) {
-            constexpr int m = decltype(mc)::value;
-            constexpr int ACT = decltype(ac)::value;
-            const int pp = wave * (32 * MREP) + m * 32 + c32;
-            const int pr = pp / TW, pc = pp % TW;
-            int orow = oh0 + pr, obase = b * p.Hout;      // output row inside its image, first output row of the image
-            bool valid = pr < p.TH && ow0 + pc < p.Wout;
-            if (p.vout > 0) {
-                const int vb = orow / p.vout;
-                orow -= vb * p.vout;
-                valid = valid && vb < p.vbatch;
-                obase = vb * p.Hout;
-            }
-            valid = valid && orow < p.Hout;
-            const size_t pix = (size_t)(obase + orow) * p.Wout + ow0 + pc;
-            // residual: all loads of this fragment are issued up front (clamped address instead of a divergent
-            // branch), so the epilogue pays one memory latency, not one per register quad
-            const bool has_res = p.res != nullptr;      // uniform
-            bf16x4 rr[NREP][4];
-            if (has_res) {
-#pragma unroll
-                for (int n = 0; n < NREP; ++n)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int co = nt * (NREP * 32) + n * 32 + 8 * i + 4 * g;
-                        const bool ok = valid && co < p.Cout;
-                        rr[n][i] = *(const bf16x4 *)(p.res + (ok ? pix * p.res_cs + co : (size_t)0));
-                    }
-            }
-#pragma unroll
-            for (int n = 0; n < NREP; ++n) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int cl = n * 32 + 8 * i + 4 * g;
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[m][n][4 * i + j];
-                    act4<ACT>(v);
-                    if (has_res) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += p.res_scale * (float)rr[n][i][j];
-                    }
-                    bf16x4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)v[j];
-                    *(bf16x4 *)(wreg + c32 * RSO + cl * 2) = o;
-                }
-            }
-            // the tile is private to this wave: order the LDS writes before the cross-lane reads
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int it = 0; it < 32 / PIXPI; ++it) {
-                const int r = it * PIXPI + lane / PPR, piece = lane % PPR;
-                const uint4 v = *(const uint4 *)(wreg + r * RSO + piece * 16);
-                const int pq = wave * (32 * MREP) + m * 32 + r;
-                const int qr = pq / TW, qc = pq % TW;
-                const int co = nt * (NREP * 32) + piece * 8;
-                int srow = oh0 + qr, sbase = b * p.Hout;
-                bool sok = qr < p.TH && ow0 + qc < p.Wout && co < p.Cout;
-                if (p.vout > 0) {
-                    const int vb = srow / p.vout;
-                    srow -= vb * p.vout;
-                    sok = sok && vb < p.vbatch;
-                    sbase = vb * p.Hout;
-                }
-                if (sok && srow < p.Hout) {
-                    const size_t opix = (size_t)(sbase + srow) * p.Wout + ow0 + qc;
-                    __bf16 *dst = co < p.split ? (__bf16 *)p.y + opix * p.y_cs + co : p.y2 + opix * p.y2_cs + (co - p.split);
-                    *(uint4 *)dst = v;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-        };
-        // ACTK >= 0: the activation is a compile-time constant of this kernel (small code); ACTK < 0: one
-        // uniform branch on the activation kind for the whole epilogue
-        auto run = [&](auto ac) __attribute__((always_inline)) {
-            static_for<MREP>([&](auto mc) __attribute__((always_inline)) { epilogue(mc, ac); });
-        };
-        if constexpr (ACTK >= 0) {
-            run(std::integral_constant<int, ACTK>{});
-        } else {
-            switch (p.act) {
-            case YAMD_ACT_LEAKY: run(std::integral_constant<int, YAMD_ACT_LEAKY>{}); break;
-            case YAMD_ACT_MISH: run(std::integral_constant<int, YAMD_ACT_MISH>{}); break;
-            case YAMD_ACT_RELU: run(std::integral_constant<int, YAMD_ACT_RELU>{}); break;
-            case YAMD_ACT_SILU: run(std::integral_constant<int, YAMD_ACT_SILU>{}); break;
-            default: run(std::integral_constant<int, YAMD_ACT_NONE>{}); break;
-            }
-        }
-    }
     YAMD_STAMP(4);
 }
 
@@ -521,17 +652,19 @@ int launch_conv(const ConvParams &p, int batch, hipStream_t stream)
 {
     constexpr int WBYTES = KS * KS * (CK / 16) * NREP * 1024;
     const int NPH = (p.TH - 1) * S + KS;
-    size_t lds = ((size_t)WBYTES + (size_t)ConvLds<KS, S, TW, CK>::image_bytes(NPH)) * STAGES;
+    size_t lds = (size_t)WBYTES + (size_t)ConvLds<KS, S, TW, CK>::image_bytes(NPH);
     const size_t epi = (size_t)NW * 32 * (OUT_F32 ? NREP * 128 + 16 : NREP * 64 + 16);   // epilogue staging tiles
     if (lds < epi) lds = epi;
+    lds *= STAGES;      // two images: each holds a chunk or, between two cout tiles, the epilogue tiles
     YAMD_REQUIRE(lds <= 160 * 1024, "conv tile needs %zu bytes of LDS", lds);
     auto kern = conv_igemm_kernel<KS, S, TW, MREP, NREP, CK, OUT_F32, ACTK, NW, STAGES>;
     {
         const int rc = KernelAttr<&conv_igemm_kernel<KS, S, TW, MREP, NREP, CK, OUT_F32, ACTK, NW, STAGES>, 160 * 1024>::ensure();
         if (rc != YAMD_OK) return rc;
     }
-    const long long total = (long long)batch * p.tiles_y * p.tiles_x * p.n_tiles;
+    const long long total = (long long)batch * p.tiles_y * p.tiles_x * (STAGES == 2 ? 1 : p.n_tiles);
     YAMD_REQUIRE(total > 0 && total < (1ll << 31) - 8, "conv grid out of range");
+    YAMD_REQUIRE((long long)(p.vout > 0 ? p.vbatch : batch) * p.Hout * p.Wout < (1ll << 31), "more than 2^31 output pixels in one launch");
     ConvParams q = p;
     q.total_tiles = (int)total;
     const long long grid = (total + 7) / 8 * 8;      // a multiple of the XCD count; surplus workgroups exit at once
