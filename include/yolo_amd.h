@@ -283,6 +283,22 @@ int yamd_stem_conv(int mode, const float *images, int batch, int h, int w, const
                    const float *bias_packed, int cout, int act, void *y, int y_cstride, void *stream);
 
 /* ----------------------------------------------------------------------------------------
+ * The first two layers of a backbone in one launch: a stride-2 stem (YAMD_STEM_FOCUS or YAMD_STEM_K3S2, as above)
+ * followed by Conv2d(c1, c2, 3, 2, 1) + bias + act, i.e. `x = self.stem(x)` and the first module of `self.dark2`
+ * (yolov5/YoloV5Body.py:139-141,160-161, yolov8/YoloV8Body.py:124-126,143-144).  Same result as yamd_stem_conv into a
+ * (batch, h/2, w/2, c1) bf16 tensor followed by yamd_conv2d_bias_act on it (the intermediate is rounded to bf16 in
+ * both), but that tensor, the largest activation of the network, is never written to memory.
+ * c1 = 32 or 64 (the stem's cout); c2 a multiple of 8, at most 128 for c1 = 32 and 64 for c1 = 64.
+ * w2: (c2, c1, 3, 3) fp32 with BN folded, packed on the host; bias_packed: 128 floats.  y: (batch, h/4, w/4, *) bf16.
+ * ---------------------------------------------------------------------------------------- */
+int64_t yamd_stem_conv2_packed_elems(int c1, int c2);   /* bf16 elements of the second conv's packed weights; 0 = unsupported */
+int yamd_stem_conv2_pack_weights(const float *w2_host, const float *bias2_host, int c1, int c2, void *w2_packed_host,
+                                 float *bias2_packed_host);
+int yamd_stem_conv2(int mode, const float *images, int batch, int h, int w, const void *w1_packed,
+                    const float *b1_packed, int c1, int act1, const void *w2_packed, const float *b2_packed, int c2,
+                    int act2, void *y, int y_cstride, void *stream);
+
+/* ----------------------------------------------------------------------------------------
  * Measurement helpers for the benchmark's roofline denominators; no counterpart in the reference and not on the
  * detection path.
  *   yamd_microbench_mfma_bf16: `blocks` workgroups of 4 wavefronts, each wavefront issues 4*iters

@@ -11,12 +11,14 @@ stages = int(sys.argv[13]) if len(sys.argv) > 13 else 1
 tag = f"{k}{s}_{tw}_{mrep}{nrep}_{ck}_{nw}_{stages}"
 VARS = {"product": None, "no staging (barriers kept)": 1, "no MFMA": 2, "no staging, no barriers": 3}
 if len(sys.argv) > 13 and int(sys.argv[13]) == 2: VARS = {"product": None, "no MFMA": 2}
+if os.environ.get("ABLATE_TAG"):
+    VARS = {"product": None}; tag += "_" + os.environ["ABLATE_TAG"]
 if os.environ.get("SKEW_BUILD") or os.environ.get("CONV_SKEW"):
     VARS = {"product": None}; tag += "_skew"
 def so(v): return os.path.join(ROOT, "scratch", f"libconv_ablate_{tag}_{v or 0}.so")
 if mode == "build":
     for name, v in VARS.items():
-        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared", f"-I{ROOT}/yolo_amd/csrc", f"-I{ROOT}/include",
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared"] + ([f"-I{os.environ['ABLATE_INC']}"] if os.environ.get("ABLATE_INC") else []) + [f"-I{ROOT}/yolo_amd/csrc", f"-I{ROOT}/include",
                f"-DTR_KS={k}", f"-DTR_S={s}", f"-DTR_TW={tw}", f"-DTR_MREP={mrep}", f"-DTR_NREP={nrep}", f"-DTR_CK={ck}", f"-DTR_NW={nw}", f"-DTR_STAGES={stages}"]
         if v: cmd.append(f"-DYAMD_CONV_ABLATE={v}")
         if os.environ.get("SKEW_BUILD"): cmd.append("-DYAMD_CONV_SKEW")

@@ -20,7 +20,7 @@ ops = []
 for op in prog.ops:
     fl, by = prog.op_cost(op, B)
     kind = op[0]
-    name_ = getattr(op[1], "name", kind) if kind in ("conv", "stem") else kind
+    name_ = getattr(op[1], "name", kind) if kind in ("conv", "stem", "stem2") else kind
     desc = ""
     if kind == "conv":
         d = op[1].desc

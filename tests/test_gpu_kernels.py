@@ -421,6 +421,61 @@ def test_conv_split_output(gpu_device, k, s, cin, cout, split, H, W):
                                             y1.shape[-1], y2.data_ptr(), y2.shape[-1], split + 4, Bn, H, W, L.current_stream()) != 0
 
 
+@pytest.mark.parametrize("mode,c1,c2,H,W,act1,act2", [
+    ("focus", 32, 64, 64, 128, 1, 1),      # YOLOv5-s: Focus stem, then dark2.0; 16 x 32 outputs = whole 4 x 16 tiles
+    ("focus", 32, 64, 72, 88, 1, 1),       # 18 x 22 outputs: tiles cut by the bottom and right edges
+    ("k3s2", 32, 64, 96, 160, 1, 1),       # YOLOv8-s: 3x3 stride-2 stem
+    ("k3s2", 32, 128, 40, 72, 2, 4),       # four cout fragments (two per wavefront), other activations
+    ("k3s2", 32, 40, 52, 36, 1, 0),        # second conv's last cout fragment partly filled, no activation
+    ("focus", 64, 64, 44, 68, 1, 3),       # 64-channel stem output (4 k-steps per tap)
+    ("k3s2", 64, 24, 36, 40, 4, 1),        # a single cout fragment: half of the wavefronts have no second-conv work
+])
+def test_stem_and_next_conv_fused(gpu_device, mode, c1, c2, H, W, act1, act2):
+    """yamd_stem_conv2 against torch: stem from the fp32 image, its output rounded to bf16 (what the unfused path
+    stores), then Conv2d(c1, c2, 3, 2, 1); the output goes into a channel slice of a wider buffer."""
+    from yolo_amd import lib as L
+    from yolo_amd.engine import StemConv2Layer, StemLayer
+    g = torch.Generator().manual_seed(H * 13 + c1 + c2)
+    Bn = 3
+    cin = 12 if mode == "focus" else 3
+    x = torch.rand((Bn, 3, H, W), generator=g)
+    w1 = _bf16_round(torch.randn((c1, cin, 3, 3), generator=g) * (2.0 / (cin * 9)) ** 0.5)
+    b1 = torch.randn((c1,), generator=g) * 0.5
+    w2 = _bf16_round(torch.randn((c2, c1, 3, 3), generator=g) * (2.0 / (c1 * 9)) ** 0.5)
+    b2 = torch.randn((c2,), generator=g) * 0.5
+    xb = _bf16_round(x)
+    if mode == "focus":
+        xf = torch.cat((xb[..., ::2, ::2], xb[..., 1::2, ::2], xb[..., ::2, 1::2], xb[..., 1::2, 1::2]), 1)
+        mid = F.conv2d(xf, w1, b1, stride=1, padding=1)
+    else:
+        mid = F.conv2d(xb, w1, b1, stride=2, padding=1)
+    mid = _bf16_round(_act(mid, act1))
+    want = _act(F.conv2d(mid, w2, b2, stride=2, padding=1), act2)
+    stem = StemLayer("t", mode, w1, b1, act1)
+    assert StemConv2Layer.supported(stem, c2)
+    layer = StemConv2Layer(stem, "t2", w2, b2, act2)
+    layer.to(gpu_device)
+    Ho, Wo = want.shape[2], want.shape[3]
+    y = torch.full((Bn, Ho, Wo, c2 + 16), -3.0, dtype=torch.bfloat16, device=gpu_device)
+    xd = x.to(gpu_device)
+    L.check(L.LIB.yamd_stem_conv2(stem.mode, xd.data_ptr(), Bn, H, W, stem.w_dev.data_ptr(), stem.b_dev.data_ptr(), c1, act1,
+                                  layer.w_dev.data_ptr(), layer.b_dev.data_ptr(), c2, act2, y.data_ptr() + 8 * 2, y.shape[-1],
+                                  L.current_stream()), "stem_conv2")
+    torch.cuda.synchronize()
+    yc = y.cpu().float()
+    assert torch.all(yc[..., :8] == -3.0) and torch.all(yc[..., 8 + c2:] == -3.0)
+    got = yc[..., 8:8 + c2].permute(0, 3, 1, 2)
+    err = (got - want).double()
+    assert float(err.norm() / want.double().norm()) <= 6e-3
+    # a stem value that lands on the other side of a bf16 rounding boundary than torch's moves one product by 2^-8
+    assert float(err.abs().max()) <= 3e-2 * float(want.abs().max())
+    # shapes the fused form does not take are refused, not mis-computed
+    assert L.LIB.yamd_stem_conv2_packed_elems(48, 96) == 0 and L.LIB.yamd_stem_conv2_packed_elems(64, 128) == 0
+    assert L.LIB.yamd_stem_conv2(0, xd.data_ptr(), Bn, H, W, stem.w_dev.data_ptr(), stem.b_dev.data_ptr(), c1, act1,
+                                 layer.w_dev.data_ptr(), layer.b_dev.data_ptr(), c2, act2, y.data_ptr(), y.shape[-1],
+                                 L.current_stream()) != 0
+
+
 @pytest.mark.parametrize("mode,cout,H,W,act", [("k3s1", 32, 40, 72, 1), ("k3s1", 64, 33, 35, 2), ("k3s2", 32, 64, 96, 1),
                                                ("k3s2", 48, 30, 70, 4), ("k3s2", 16, 18, 34, 3), ("focus", 32, 64, 128, 1),
                                                ("focus", 64, 36, 44, 1)])

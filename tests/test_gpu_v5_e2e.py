@@ -153,14 +153,16 @@ def test_full_batch_properties(gpu_device):
         assert np.array_equal(idx[b, :counts[b]].astype(np.int64), want_idx[b])
 
 
-def test_v5s_layer_by_layer_vs_oracle(gpu_device):
+def test_v5s_layer_by_layer_vs_oracle(gpu_device, monkeypatch):
     """Per-layer gate: every checked layer (or block) is re-computed by the fp32 CPU oracle FROM THE GPU's OWN INPUT of
     that layer, so the difference is that layer's bf16 rounding alone: relative L2 <= 1e-2 for single convs of every
     kind (stem from the image, 3x3 stride 2, 1x1, the SPP block with its pools, the fp32 head conv) and for whole C3
-    blocks (four to eight convs chained)."""
+    blocks (four to eight convs chained).  The stem and the conv after it normally run as one launch that never writes
+    the stem's output; here they run apart so that each can be looked at (the fused launch has its own test below)."""
     import torch.nn.functional as F
     from oracle import v5_ref as R
     from yolo_amd.init import seeded_images, seeded_state_dict
+    monkeypatch.setenv("YAMD_NO_STEM_FUSION", "1")
     p, m = _model(128, 21, gpu_device)
     sd = seeded_state_dict(m, seed=21, mode="spread")
     imgs_np = seeded_images(2, 128, seed=21)
@@ -188,3 +190,38 @@ def test_v5s_layer_by_layer_vs_oracle(gpu_device):
         }
     worst = {k: _rel_l2(got.numpy(), want.numpy()) for k, (want, got) in checks.items()}
     assert max(worst.values()) <= 1e-2, worst
+
+
+@pytest.mark.parametrize("size", [128, 160])
+def test_v5s_fused_stem_and_next_conv(gpu_device, monkeypatch, size):
+    """The stem and dark2.0 as one launch: against the fp32 oracle chained over both layers (its stem output rounded to
+    bf16, as the unfused GPU path stores it), and against the unfused GPU path, whose only difference is the order in
+    which the MFMAs accumulate.  160 = tiles cut by the right and bottom image edges (40 x 40 outputs, 4 x 16 tiles)."""
+    from oracle import v5_ref as R
+    from yolo_amd.init import seeded_images, seeded_state_dict
+    imgs = torch.from_numpy(seeded_images(3, size, seed=5))
+    p, m = _model(size, 33, gpu_device)
+    sd = seeded_state_dict(m, seed=33, mode="spread")
+    m.raw_heads(imgs.to(gpu_device))
+    prog = m.program()
+    assert any(op[0] == "stem2" for op in prog.ops), "the fused launch is not in the program"
+    with pytest.raises(Exception, match="not materialised"):
+        prog.read_view(prog.taps["stem"], 3, gpu_device)
+    fused = prog.read_view(prog.taps["dark2.0"], 3, gpu_device).cpu()
+    monkeypatch.setenv("YAMD_NO_STEM_FUSION", "1")
+    p2, m2 = _model(size, 33, gpu_device)
+    m2.raw_heads(imgs.to(gpu_device))
+    prog2 = m2.program()
+    assert not any(op[0] == "stem2" for op in prog2.ops)
+    apart = prog2.read_view(prog2.taps["dark2.0"], 3, gpu_device).cpu()
+    bb = "body_net.backbone."
+    with torch.no_grad():
+        focus = torch.cat((imgs[..., ::2, ::2], imgs[..., 1::2, ::2], imgs[..., ::2, 1::2], imgs[..., 1::2, 1::2]), 1)
+        stem = R._conv_block(sd, bb + "stem.conv", focus.bfloat16().float()).bfloat16().float()
+        want = R._conv_block(sd, bb + "dark2.0", stem, 2)
+    assert fused.shape == want.shape == apart.shape
+    assert _rel_l2(fused.numpy(), want.numpy()) <= 1e-2
+    assert _rel_l2(fused.numpy(), apart.numpy()) <= 4e-3
+    # the border rows and columns (zero padding of both layers) separately: an indexing slip there hides in the total
+    for sl in (np.s_[:, :, 0], np.s_[:, :, -1], np.s_[:, :, :, 0], np.s_[:, :, :, -1]):
+        assert _rel_l2(fused.numpy()[sl], apart.numpy()[sl]) <= 6e-3

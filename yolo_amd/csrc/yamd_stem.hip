@@ -170,6 +170,292 @@ int launch_stem(const StemParams &p, int batch, hipStream_t st)
     return YAMD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The first TWO convs of a backbone in one kernel: the stem above, then a 3x3 stride-2 conv (pad 1) on its output.
+// The stem's output (the largest activation of the network) is never written to memory: a workgroup computes the
+// stem on the (2*4+1) x (2*16+1) pixels that its 4 x 16 tile of the second conv needs, keeps them in LDS as bf16 (the
+// same rounding the unfused path applies when it stores them) and runs the second conv from there.  Pixels of that
+// region outside the stem's output are the second conv's zero padding.  The stem is recomputed on the overlap between
+// neighbouring tiles (297 pixels for 256 needed: +16 %).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int F_TH = 4, F_TW = 16;                          // tile of the second conv's output: 2 fragments of 2 rows x 16
+constexpr int F_IR = 2 * F_TH + 1, F_IC = 2 * F_TW + 1;     // stem pixels under the tile
+constexpr int F_IPIX = F_IR * F_IC;
+constexpr int F_IFRAG = (F_IPIX + 31) / 32;
+constexpr int F_HALF = (F_IC + 1) / 2;                      // a row of stem pixels is stored even columns first, then odd:
+constexpr int F_CROW = 2 * F_HALF;                          // the stride-2 taps of neighbouring outputs are neighbours in LDS
+
+template <int KS, int S>
+struct FusedGeom {
+    static constexpr int PAD = KS == 6 ? 2 : 1;
+    static constexpr int XO = (PAD + S) & 1;                       // the patch starts XO columns early: at an even image column
+    static constexpr int R = (F_IR - 1) * S + KS;                  // image patch rows
+    static constexpr int CW = ((F_IC - 1) * S + KS + XO + 1) / 2 * 2;   // patch columns, even
+    static constexpr int K = 3 * KS * KS;
+    static constexpr int KSTEPS = (K + 15) / 16;
+    static constexpr int PATCH = 3 * R * CW;
+    static constexpr int off(int k)
+    {
+        if (k >= K) return -1;
+        const int ch = k / (KS * KS), rem = k % (KS * KS);
+        return (ch * R + rem / KS) * CW + rem % KS;
+    }
+};
+
+struct FusedParams {
+    const float *img;
+    const bf16x8 *w1;      // stem weights, [kstep][ncol][lane] fragments
+    const float *b1;
+    const char *w2;        // second conv, [tap][kstep][ncol] fragments of 1 KB
+    const float *b2;
+    __bf16 *y;
+    int H, W, H1, W1, H2, W2, C2, y_cs, act1, act2, tiles_x, tiles_y, total_tiles;
+};
+
+// SILU: both activations are SiLU (compile-time, the usual case); otherwise they are looked up per value
+template <int KS, int S, int NREP1, int NREP2, bool SILU>
+__global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
+{
+    using G = FusedGeom<KS, S>;
+    constexpr int C1 = NREP1 * 32;
+    constexpr int KS2 = C1 / 16;                           // k-steps per tap of the second conv
+    constexpr int RS2 = C1 * 2 + 16;                       // bytes per stem pixel in LDS (padded: conflict-free 16-byte reads)
+    constexpr int RSO = NREP2 * 64 + 16;                   // bytes per pixel of the output staging tile
+    constexpr int PATCH_BYTES = ((G::PATCH + 8) * 2 + 15) / 16 * 16;
+    constexpr int STAGE_BYTES = 64 * RSO;
+    constexpr int A_BYTES = PATCH_BYTES > STAGE_BYTES ? PATCH_BYTES : STAGE_BYTES;   // patch, later the output tile
+    constexpr int I_BYTES = F_IR * F_CROW * RS2;
+    constexpr int W2_BYTES = 9 * KS2 * NREP2 * 1024;
+    constexpr int NQ = (NREP2 + 1) / 2;                    // cout fragments per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16 *patch = (__bf16 *)smem;
+    char *inter = smem + A_BYTES;
+    char *w2s = inter + I_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c32 = lane & 31, g = lane >> 5;
+
+    // second-conv weights: resident in LDS for all tiles of this workgroup
+    for (int q = tid; q < W2_BYTES / 16; q += 256) *(u32x4 *)(w2s + q * 16) = *(const u32x4 *)(p.w2 + q * 16);
+    // stem weights: one A fragment per (k step, 32-cout column), in registers
+    bf16x8 wf[G::KSTEPS][NREP1];
+#pragma unroll
+    for (int ks = 0; ks < G::KSTEPS; ++ks)
+#pragma unroll
+        for (int n = 0; n < NREP1; ++n) wf[ks][n] = p.w1[(ks * NREP1 + n) * 64 + lane];
+
+    // biases in registers for all tiles
+    f32x4 bias1[NREP1][4], bias2[NQ][4];
+#pragma unroll
+    for (int n = 0; n < NREP1; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias1[n][i] = *(const f32x4 *)(p.b1 + n * 32 + 8 * i + 4 * g);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            bias2[q][i] = *(const f32x4 *)(p.b2 + min((wave >> 1) + 2 * q, NREP2 - 1) * 32 + 8 * i + 4 * g);
+    const int act1 = SILU ? YAMD_ACT_SILU : p.act1, act2 = SILU ? YAMD_ACT_SILU : p.act2;
+
+    // The patch is loaded two columns at a time: its first column is even in the image (XO below) and so is its width,
+    // so a pair is 8-byte aligned and lies inside the image or outside it as a whole.
+    constexpr int NE = (G::PATCH / 2 + 255) / 256;
+    f32x2 pv[NE];
+    // pair of this thread -> (channel, row, first column), the same for every tile
+    int prc[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+        const int e = 2 * min(tid + u * 256, G::PATCH / 2 - 1);
+        const int c = e % G::CW, rr = e / G::CW;
+        prc[u] = ((rr / G::R) << 20) | ((rr % G::R) << 10) | c;
+    }
+    // fp32 patch of tile `t` into registers: clamped addresses and a select, no branch; one memory latency per tile
+    auto load_patch = [&](int t) __attribute__((always_inline)) {
+        const int tx = t % p.tiles_x;
+        t /= p.tiles_x;
+        const int ty = t % p.tiles_y;
+        const long long b = t / p.tiles_y;
+        const int ih0 = (2 * ty * F_TH - 1) * S - G::PAD, iw0 = (2 * tx * F_TW - 1) * S - G::PAD - G::XO;
+        const float *img = p.img + b * 3 * (long long)p.H * p.W;
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int ch = prc[u] >> 20, ih = ih0 + ((prc[u] >> 10) & 1023), iw = iw0 + (prc[u] & 1023);
+            const bool inb = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+            const f32x2 v = *(const f32x2 *)(img + (ch * p.H + min(max(ih, 0), p.H - 1)) * p.W + min(max(iw, 0), p.W - 2));
+            pv[u] = inb ? v : f32x2{0.0f, 0.0f};
+        }
+    };
+
+    // the wave's role in the second conv: pixel fragment wm (rows 2wm, 2wm+1 of the tile), cout fragments wn, wn+2
+    const int wm = wave & 1, wn = wave >> 1;
+    const int pr = wm * 2 + (c32 >> 4), pc = c32 & 15;
+    const int pixbase = ((2 * pr) * F_CROW + pc) * RS2 + g * 16;
+
+    const int tile_step = gridDim.x;
+    int tile = blockIdx.x;
+    if (tile >= p.total_tiles) return;
+    load_patch(tile);
+    for (; tile < p.total_tiles; tile += tile_step) {
+        int t = tile;
+        const int tx = t % p.tiles_x;
+        t /= p.tiles_x;
+        const int ty = t % p.tiles_y;
+        const long long b = t / p.tiles_y;
+        const int oh0 = ty * F_TH, ow0 = tx * F_TW;
+        const int ir0 = 2 * oh0 - 1, ic0 = 2 * ow0 - 1;      // first stem pixel under the tile
+
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int e = tid + u * 256;
+            if (e < G::PATCH / 2) {
+                bf16x2 o;
+                o[0] = (__bf16)pv[u][0];
+                o[1] = (__bf16)pv[u][1];
+                *(bf16x2 *)(patch + 2 * e) = o;
+            }
+        }
+        if (tid < 8) patch[G::PATCH + tid] = (__bf16)0.0f;
+        __syncthreads();
+        if (tile + tile_step < p.total_tiles) load_patch(tile + tile_step);      // in flight during this tile's MFMAs
+
+        // ---- stem on the 9 x 33 pixels under the tile, 32 at a time
+        for (int f = wave; f < F_IFRAG; f += 4) {
+            const int s_raw = f * 32 + c32, s = min(s_raw, F_IPIX - 1);
+            const int r = s / F_IC, c = s - r * F_IC;
+            const int base = (r * S) * G::CW + c * S + G::XO;  // patch origin of this lane's stem pixel
+            f32x16 acc[NREP1];
+#pragma unroll
+            for (int n = 0; n < NREP1; ++n)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[n][4 * i + j] = bias1[n][i][j];
+#pragma unroll
+            for (int ks = 0; ks < G::KSTEPS; ++ks) {
+                bf16x8 a;
+                if constexpr (KS == 6) {
+                    // (k, k+1) for even k are neighbours in a patch row; row pitch, stride and origin are even: one 32-bit read
+                    u32x4 av;
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const int o0 = G::off(ks * 16 + j), o1 = G::off(ks * 16 + 8 + j);
+                        const int idx = g ? (o1 < 0 ? G::PATCH : base + o1) : (o0 < 0 ? G::PATCH : base + o0);
+                        av[j / 2] = *(const unsigned *)(patch + idx);
+                    }
+                    a = __builtin_bit_cast(bf16x8, av);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int o0 = G::off(ks * 16 + j), o1 = G::off(ks * 16 + 8 + j);
+                        const int idx = g ? (o1 < 0 ? G::PATCH : base + o1) : (o0 < 0 ? G::PATCH : base + o0);
+                        a[j] = patch[idx];
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < NREP1; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][n], a, acc[n], 0, 0, 0);
+            }
+            // activation, bf16, into the stem image; pixels outside the stem's output are the second conv's padding
+            const int ir = ir0 + r, ic = ic0 + c;
+            const bool real = ir >= 0 && ir < p.H1 && ic >= 0 && ic < p.W1;
+            if (s_raw < F_IPIX) {
+                char *dst = inter + (r * F_CROW + (c & 1) * F_HALF + (c >> 1)) * RS2;
+#pragma unroll
+                for (int n = 0; n < NREP1; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        bf16x4 o;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = (__bf16)(real ? apply_act(acc[n][4 * i + j], act1) : 0.0f);
+                        *(bf16x4 *)(dst + (n * 32 + 8 * i + 4 * g) * 2) = o;
+                    }
+            }
+        }
+        __syncthreads();
+
+        // ---- second conv: 3x3 stride 2 from the stem image
+        f32x16 acc2[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc2[q][4 * i + j] = bias2[q][i][j];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int tapoff = (ky * F_CROW + (kx & 1) * F_HALF + (kx >> 1)) * RS2;
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                const bf16x8 a = *(const bf16x8 *)(inter + pixbase + tapoff + ks * 32);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int n = min(wn + 2 * q, NREP2 - 1);
+                    const bf16x8 wv = *(const bf16x8 *)(w2s + ((tap * KS2 + ks) * NREP2 + n) * 1024 + lane * 16);
+                    acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, a, acc2[q], 0, 0, 0);
+                }
+            }
+        }
+        // ---- output tile through LDS (the patch is dead since the last barrier), then whole pixel rows to memory
+        char *stage = smem;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int n = wn + 2 * q;
+            if (n < NREP2) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (__bf16)apply_act(acc2[q][4 * i + j], act2);
+                    *(bf16x4 *)(stage + (wm * 32 + c32) * RSO + (n * 32 + 8 * i + 4 * g) * 2) = o;
+                }
+            }
+        }
+        __syncthreads();
+        constexpr int PPR = NREP2 * 4;                       // 16-byte pieces per pixel
+        for (int e = tid; e < 64 * PPR; e += 256) {
+            const int fp = e / PPR, piece = e % PPR;
+            const int oh = oh0 + fp / F_TW, ow = ow0 + fp % F_TW, co = piece * 8;
+            if (oh < p.H2 && ow < p.W2 && co < p.C2)
+                *(uint4 *)(p.y + ((b * p.H2 + oh) * p.W2 + ow) * p.y_cs + co) = *(const uint4 *)(stage + fp * RSO + piece * 16);
+        }
+        __syncthreads();                                      // the next tile's patch overwrites the output tile
+    }
+}
+
+template <int KS, int S, int NREP1, int NREP2, bool SILU>
+int launch_stem_conv2_act(const FusedParams &p, hipStream_t st)
+{
+    using G = FusedGeom<KS, S>;
+    constexpr int C1 = NREP1 * 32, RS2 = C1 * 2 + 16, RSO = NREP2 * 64 + 16;
+    constexpr int PATCH_BYTES = ((G::PATCH + 8) * 2 + 15) / 16 * 16, STAGE_BYTES = 64 * RSO;
+    constexpr int A_BYTES = PATCH_BYTES > STAGE_BYTES ? PATCH_BYTES : STAGE_BYTES;
+    constexpr size_t LDS = (size_t)A_BYTES + (size_t)F_IR * F_CROW * RS2 + (size_t)9 * (C1 / 16) * NREP2 * 1024;
+    static_assert(LDS <= 160 * 1024, "fused stem tile does not fit LDS");
+    auto kern = stem_conv2_kernel<KS, S, NREP1, NREP2, SILU>;
+    {
+        const int rc = KernelAttr<&stem_conv2_kernel<KS, S, NREP1, NREP2, SILU>, 160 * 1024>::ensure();
+        if (rc != YAMD_OK) return rc;
+    }
+    // persistent grid: the workgroups resident at once share the tiles; each keeps the second conv's weights in LDS
+    int device = 0, cus = 0, per_cu = 0;
+    YAMD_REQUIRE(hipGetDevice(&device) == hipSuccess &&
+                     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess &&
+                     hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, 256, LDS) == hipSuccess && cus > 0,
+                 "occupancy query failed");
+    if (per_cu < 1) per_cu = 1;
+    long long grid = (long long)cus * per_cu;
+    if (grid > p.total_tiles) grid = p.total_tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, st, p);
+    YAMD_LAUNCH_CHECK();
+    return YAMD_OK;
+}
+
+template <int KS, int S, int NREP1, int NREP2>
+int launch_stem_conv2(const FusedParams &p, hipStream_t st)
+{
+    if (p.act1 == YAMD_ACT_SILU && p.act2 == YAMD_ACT_SILU) return launch_stem_conv2_act<KS, S, NREP1, NREP2, true>(p, st);
+    return launch_stem_conv2_act<KS, S, NREP1, NREP2, false>(p, st);
+}
+
 bool stem_mode(int mode, int &ks, int &s)
 {
     switch (mode) {
@@ -252,4 +538,86 @@ extern "C" int yamd_stem_conv(int mode, const float *images, int batch, int h, i
     if (mode == YAMD_STEM_K3S1) return launch_stem<3, 1>(p, batch, st);
     if (mode == YAMD_STEM_K3S2) return launch_stem<3, 2>(p, batch, st);
     return launch_stem<6, 2>(p, batch, st);
+}
+
+extern "C" int64_t yamd_stem_conv2_packed_elems(int c1, int c2)
+{
+    // the second conv's weights stay in LDS: 9 * (c1 / 16) KB per 32 couts
+    if ((c1 != 32 && c1 != 64) || c2 <= 0 || c2 > (c1 == 32 ? 128 : 64) || c2 % 8 != 0) return 0;
+    return (int64_t)9 * (c1 / 16) * ((c2 + 31) / 32) * 512;
+}
+
+extern "C" int yamd_stem_conv2_pack_weights(const float *w, const float *bias, int c1, int c2, void *w_packed, float *bias_packed)
+{
+    YAMD_REQUIRE(w && w_packed && bias_packed, "null argument");
+    YAMD_REQUIRE(yamd_stem_conv2_packed_elems(c1, c2) > 0, "fused second conv: cin=%d (32 or 64), cout=%d (multiple of 8; <= 128 for cin 32, <= 64 for cin 64)", c1, c2);
+    const int ks2 = c1 / 16, nrep = (c2 + 31) / 32;
+    __bf16 *out = (__bf16 *)w_packed;
+    for (int tap = 0; tap < 9; ++tap)
+        for (int ks = 0; ks < ks2; ++ks)
+            for (int n = 0; n < nrep; ++n)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = n * 32 + (lane & 31), ci = ks * 16 + (lane >> 5) * 8 + j;
+                        const float v = co < c2 ? w[((size_t)co * c1 + ci) * 9 + tap] : 0.0f;
+                        out[((((size_t)tap * ks2 + ks) * nrep + n) * 64 + lane) * 8 + j] = (__bf16)v;
+                    }
+    for (int c = 0; c < 128; ++c) bias_packed[c] = (bias && c < c2) ? bias[c] : 0.0f;
+    return YAMD_OK;
+}
+
+extern "C" int yamd_stem_conv2(int mode, const float *images, int batch, int h, int w, const void *w1_packed,
+                               const float *b1_packed, int c1, int act1, const void *w2_packed, const float *b2_packed,
+                               int c2, int act2, void *y, int y_cstride, void *stream)
+{
+    YAMD_REQUIRE(images && w1_packed && b1_packed && w2_packed && b2_packed && y, "null argument");
+    int ks, s;
+    YAMD_REQUIRE(stem_mode(mode, ks, s) && s == 2, "the fused form takes a stride-2 stem (mode %d)", mode);
+    YAMD_REQUIRE(batch > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, "bad image shape %dx%dx%d", batch, h, w);
+    YAMD_REQUIRE(yamd_stem_conv2_packed_elems(c1, c2) > 0, "fused second conv: cin=%d (32 or 64), cout=%d (multiple of 8; <= 128 for cin 32, <= 64 for cin 64)", c1, c2);
+    YAMD_REQUIRE(act1 >= YAMD_ACT_NONE && act1 <= YAMD_ACT_RELU && act2 >= YAMD_ACT_NONE && act2 <= YAMD_ACT_RELU, "unknown activation");
+    YAMD_REQUIRE(y_cstride >= c2 && y_cstride % 8 == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)w1_packed % 16) == 0 &&
+                     ((uintptr_t)w2_packed % 16) == 0 && ((uintptr_t)b1_packed % 16) == 0 && ((uintptr_t)b2_packed % 16) == 0,
+                 "fused stem output / weights need 16-byte alignment (cstride=%d)", y_cstride);
+    FusedParams p;
+    p.img = images;
+    p.w1 = (const bf16x8 *)w1_packed;
+    p.b1 = b1_packed;
+    p.w2 = (const char *)w2_packed;
+    p.b2 = b2_packed;
+    p.y = (__bf16 *)y;
+    p.H = h;
+    p.W = w;
+    const int pad = ks == 6 ? 2 : 1;
+    p.H1 = (h + 2 * pad - ks) / 2 + 1;
+    p.W1 = (w + 2 * pad - ks) / 2 + 1;
+    p.H2 = (p.H1 - 1) / 2 + 1;
+    p.W2 = (p.W1 - 1) / 2 + 1;
+    p.C2 = c2;
+    p.y_cs = y_cstride;
+    p.act1 = act1;
+    p.act2 = act2;
+    p.tiles_x = ceil_div(p.W2, F_TW);
+    p.tiles_y = ceil_div(p.H2, F_TH);
+    const long long total = (long long)batch * p.tiles_y * p.tiles_x;
+    YAMD_REQUIRE(total > 0 && total < (1ll << 31), "fused stem grid out of range");
+    YAMD_REQUIRE(3ll * h * w < (1ll << 31) && w >= 2, "image too large or too narrow");
+    YAMD_REQUIRE((long long)batch * p.H2 * p.W2 * y_cstride < (1ll << 62), "output too large");
+    p.total_tiles = (int)total;
+    hipStream_t st = (hipStream_t)stream;
+    const int nrep2 = (c2 + 31) / 32;
+    if (c1 == 32) {
+        switch (nrep2 * 10 + (ks == 6)) {
+        case 11: return launch_stem_conv2<6, 2, 1, 1>(p, st);
+        case 21: return launch_stem_conv2<6, 2, 1, 2>(p, st);
+        case 31: return launch_stem_conv2<6, 2, 1, 3>(p, st);
+        case 41: return launch_stem_conv2<6, 2, 1, 4>(p, st);
+        case 10: return launch_stem_conv2<3, 2, 1, 1>(p, st);
+        case 20: return launch_stem_conv2<3, 2, 1, 2>(p, st);
+        case 30: return launch_stem_conv2<3, 2, 1, 3>(p, st);
+        default: return launch_stem_conv2<3, 2, 1, 4>(p, st);
+        }
+    }
+    if (ks == 6) return nrep2 == 1 ? launch_stem_conv2<6, 2, 2, 1>(p, st) : launch_stem_conv2<6, 2, 2, 2>(p, st);
+    return nrep2 == 1 ? launch_stem_conv2<3, 2, 2, 1>(p, st) : launch_stem_conv2<3, 2, 2, 2>(p, st);
 }

@@ -105,6 +105,40 @@ class StemLayer:
             self.b_dev = self.b_host.to(device)
 
 
+class StemConv2Layer:
+    """A stride-2 stem and the 3x3 stride-2 conv that follows it, run as one launch (``yamd_stem_conv2``): the stem's
+    output is never written to memory."""
+
+    def __init__(self, stem: StemLayer, name: str, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int):
+        w = weight.detach().to(torch.float32).cpu().contiguous()
+        cout, cin, k, _ = w.shape
+        assert k == 3 and cin == stem.cout
+        self.stem, self.name, self.act, self.cout, self.cin_real = stem, name, act, cout, cin
+        self.macs_per_pixel = cout * cin * 9
+        b = None if bias is None else bias.detach().to(torch.float32).cpu().contiguous()
+        n = LIB.yamd_stem_conv2_packed_elems(cin, cout)
+        if n <= 0:
+            raise _lib.YamdError(f"stem_conv2[{name}]: cin={cin} cout={cout} not supported")
+        self.w_host = torch.empty(n, dtype=torch.int16)
+        self.b_host = torch.empty(128, dtype=torch.float32)
+        _lib.check(LIB.yamd_stem_conv2_pack_weights(w.data_ptr(), None if b is None else b.data_ptr(), cin, cout,
+                                                    self.w_host.data_ptr(), self.b_host.data_ptr()),
+                   f"stem_conv2_pack_weights[{name}]")
+        self.w_dev: Optional[torch.Tensor] = None
+        self.b_dev: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def supported(stem: StemLayer, cout: int) -> bool:
+        return stem.mode in (StemLayer.MODES["k3s2"], StemLayer.MODES["focus"]) and \
+            LIB.yamd_stem_conv2_packed_elems(stem.cout, cout) > 0
+
+    def to(self, device) -> None:
+        self.stem.to(device)
+        if self.w_dev is None or self.w_dev.device != torch.device(device):
+            self.w_dev = self.w_host.to(device)
+            self.b_dev = self.b_host.to(device)
+
+
 class Program:
     def __init__(self, img_h: int, img_w: int):
         self.img_h, self.img_w = img_h, img_w
@@ -118,6 +152,7 @@ class Program:
         self._alloc: Dict[Tuple[int, str], Dict[str, torch.Tensor]] = {}
         self._n = 0
         self.span_sink: Optional[list] = None    # when set, every run() appends its conv spans here (see run)
+        self.fused_away: set = set()             # buffers whose producer was merged into its consumer: never written
 
     # ---- recording -------------------------------------------------------------------------------
     def buffer(self, h: int, w: int, c: int, dtype=torch.bfloat16, name: Optional[str] = None) -> View:
@@ -162,6 +197,22 @@ class Program:
             assert (out.h, out.w, out.c) == (ho, wo, cout), (name, out, ho, wo, cout)
             self.stems.append(layer)
             self.ops.append(("stem", layer, out))
+            return out
+        if (self.ops and self.ops[-1][0] == "stem" and self.ops[-1][2] == x and k == 3 and stride == 2 and residual is None
+                and out2 is None and not out_f32 and StemConv2Layer.supported(self.ops[-1][1], cout)
+                and not os.environ.get("YAMD_NO_STEM_FUSION")):
+            # the stem's only reader follows it directly: both run as one launch and the stem's output, the largest
+            # activation of the network, is never written (a later reader of that buffer would find it unwritten, so the
+            # buffer is dropped: recording such a reader fails in resolve())
+            _, stem_layer, stem_out = self.ops.pop()
+            del self.buffers[stem_out.buf]
+            self.fused_away.add(stem_out.buf)
+            layer = StemConv2Layer(stem_layer, name, weight, bias, act)
+            if out is None:
+                out = self.buffer(ho, wo, cout)
+            assert (out.h, out.w, out.c) == (ho, wo, cout), (name, out, ho, wo, cout)
+            self.stems.append(layer)
+            self.ops.append(("stem2", layer, out))
             return out
         from . import tuning
         layer = ConvLayer(name, weight, bias, stride, act, x.c, out_f32,
@@ -369,10 +420,13 @@ class Program:
         """The current contents of an activation view as a float32 NCHW tensor (after a ``run`` with this batch)."""
         bufs = self._buffers_for(batch, device)
         buf, coff = self.resolve(v)
+        if buf in self.fused_away:
+            raise _lib.YamdError(f"activation '{buf}' is not materialised: its layer runs fused with the next one "
+                                 "(set YAMD_NO_STEM_FUSION=1 before building the model to inspect it)")
         return bufs[buf][..., coff:coff + v.c].permute(0, 3, 1, 2).float().contiguous()
 
     def n_conv_launches(self) -> int:
-        return sum(1 for op in self.ops if op[0] in ("conv", "stem"))
+        return sum(1 for op in self.ops if op[0] in ("conv", "stem", "stem2"))
 
     def conv_macs_per_image(self) -> int:
         total = 0
@@ -381,6 +435,8 @@ class Program:
                 total += op[1].macs_per_pixel * op[3].h * op[3].w
             elif op[0] == "stem":
                 total += op[1].macs_per_pixel * op[2].h * op[2].w
+            elif op[0] == "stem2":      # the MACs of the two layers, not of the fused kernel (which recomputes tile overlaps)
+                total += op[1].macs_per_pixel * op[2].h * op[2].w + op[1].stem.macs_per_pixel * (self.img_h // 2) * (self.img_w // 2)
         return total
 
     def activation_bytes_per_image(self) -> int:
@@ -405,6 +461,11 @@ class Program:
             _, layer, out = op
             px = batch * out.h * out.w
             return 2.0 * layer.macs_per_pixel * px, float(batch * self.img_h * self.img_w * 3 * 4 + px * out.c * 2)
+        if kind == "stem2":
+            _, layer, out = op
+            px = batch * out.h * out.w
+            flops = 2.0 * layer.macs_per_pixel * px + 2.0 * layer.stem.macs_per_pixel * batch * (self.img_h // 2) * (self.img_w // 2)
+            return flops, float(batch * self.img_h * self.img_w * 3 * 4 + px * out.c * 2 + layer.macs_per_pixel * 2)
         if kind == "focus":
             return 0.0, float(batch * self.img_h * self.img_w * 3 * 4 + batch * op[1].h * op[1].w * 16 * 2)
         if kind == "nhwc16":
@@ -461,7 +522,7 @@ class Program:
         for op in self.ops:
             kind = op[0]
             if conv_spans is not None:
-                is_conv = kind in ("conv", "stem")
+                is_conv = kind in ("conv", "stem", "stem2")
                 if is_conv and span_open is None:
                     span_open = torch.cuda.Event(enable_timing=True)
                     span_open.record()
@@ -492,6 +553,13 @@ class Program:
                 yp, ycs = P(bufs, out)
                 _lib.check(LIB.yamd_stem_conv(layer.mode, images.data_ptr(), B, H, W, layer.w_dev.data_ptr(),
                                               layer.b_dev.data_ptr(), layer.cout, layer.act, yp, ycs, st), f"stem[{layer.name}]")
+            elif kind == "stem2":
+                _, layer, out = op
+                yp, ycs = P(bufs, out)
+                st1 = layer.stem
+                _lib.check(LIB.yamd_stem_conv2(st1.mode, images.data_ptr(), B, H, W, st1.w_dev.data_ptr(), st1.b_dev.data_ptr(),
+                                               st1.cout, st1.act, layer.w_dev.data_ptr(), layer.b_dev.data_ptr(), layer.cout,
+                                               layer.act, yp, ycs, st), f"stem_conv2[{layer.name}]")
             elif kind == "focus":
                 yp, ycs = P(bufs, op[1])
                 _lib.check(LIB.yamd_focus_pack(images.data_ptr(), yp, ycs, B, H, W, st), "focus")
@@ -531,7 +599,7 @@ class Program:
             if timings is not None:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
-                if kind == "stem":          # reported with the convs: it is the first conv layer
+                if kind in ("stem", "stem2"):          # reported with the convs: the first conv layer(s)
                     timings.append(("conv", op[1].name, ev0, ev1) + self.op_cost(op, B))
                 else:
                     timings.append((kind, op[1].name if kind == "conv" else kind, ev0, ev1) + self.op_cost(op, B))

@@ -20,7 +20,7 @@ EXPORTS = [
     "yamd_last_error", "yamd_version", "yamd_init", "yamd_conv_desc_init", "yamd_conv_desc_tune", "yamd_conv_pack_weights", "yamd_conv2d_bias_act", "yamd_conv2d_bias_act_split",
     "yamd_focus_pack", "yamd_nchw_to_nhwc16", "yamd_upsample2x", "yamd_maxpool2", "yamd_maxpool5_cascade", "yamd_maxpool3_cascade",
     "yamd_copy_channels", "yamd_depth_to_space2", "yamd_decode_ltrb_points",
-    "yamd_decode_anchor", "yamd_decode_anchor_levels", "yamd_decode_dfl", "yamd_decode_dfl_unit_conf", "yamd_decode_dfl_points", "yamd_nms_workspace_bytes", "yamd_nms_batched", "yamd_nms_static_capacity_bytes", "yamd_nms_batched_static", "yamd_compact_rows", "yamd_letterbox_workspace_bytes", "yamd_letterbox_u8", "yamd_detect_match", "yamd_stem_packed_elems", "yamd_stem_pack_weights", "yamd_stem_conv",
+    "yamd_decode_anchor", "yamd_decode_anchor_levels", "yamd_decode_dfl", "yamd_decode_dfl_unit_conf", "yamd_decode_dfl_points", "yamd_nms_workspace_bytes", "yamd_nms_batched", "yamd_nms_static_capacity_bytes", "yamd_nms_batched_static", "yamd_compact_rows", "yamd_letterbox_workspace_bytes", "yamd_letterbox_u8", "yamd_detect_match", "yamd_stem_packed_elems", "yamd_stem_pack_weights", "yamd_stem_conv", "yamd_stem_conv2_packed_elems", "yamd_stem_conv2_pack_weights", "yamd_stem_conv2",
     "yamd_microbench_mfma_bf16", "yamd_microbench_copy",
 ]
 
@@ -83,6 +83,11 @@ def _load() -> ctypes.CDLL:
     lib.yamd_stem_packed_elems.argtypes = [c_int, c_int]
     lib.yamd_stem_pack_weights.argtypes = [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     lib.yamd_stem_conv.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]
+    lib.yamd_stem_conv2_packed_elems.restype = c_int64
+    lib.yamd_stem_conv2_packed_elems.argtypes = [c_int, c_int]
+    lib.yamd_stem_conv2_pack_weights.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.yamd_stem_conv2.argtypes = [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                    c_int, c_int, c_void_p, c_int, c_void_p]
     lib.yamd_microbench_mfma_bf16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.yamd_microbench_copy.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_void_p]
     lib.yamd_letterbox_workspace_bytes.restype = c_size_t
@@ -100,7 +105,7 @@ def _load() -> ctypes.CDLL:
                                             c_void_p, c_void_p, c_int, c_void_p, c_void_p]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("yamd_last_error", "yamd_nms_workspace_bytes", "yamd_letterbox_workspace_bytes", "yamd_stem_packed_elems",
+        if name not in ("yamd_last_error", "yamd_nms_workspace_bytes", "yamd_letterbox_workspace_bytes", "yamd_stem_packed_elems", "yamd_stem_conv2_packed_elems",
                         "yamd_nms_static_capacity_bytes"):
             fn.restype = c_int
     return lib
