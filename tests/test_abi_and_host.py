@@ -92,7 +92,9 @@ def test_v5s_state_dict_and_plan():
     prog = m.program()
     # 62 convs in the reference graph; cv1+cv2 of the 8 C3 blocks run as one conv each; the first conv runs as the
     # from-the-image stem kernel
-    assert len(prog.convs) + len(prog.stems) == 54 and len(prog.stems) == 1
+    # 54 conv layers in 53 launches: the Focus stem and dark2.0 run as one
+    assert len(prog.convs) == 52 and len(prog.stems) == 1 and prog.n_conv_launches() == 53
+    assert prog.ops[0][0] == "stem2" and prog.ops[0][1].name.endswith("dark2.0") and prog.ops[0][1].stem.name.endswith("stem")
     assert abs(prog.conv_macs_per_image() * 2 / 1e9 - 16.44) < 0.01
     assert set(prog.outputs) == {"P3", "P4", "P5"}
     assert isinstance(prog, Program)

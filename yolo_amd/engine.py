@@ -208,6 +208,7 @@ class Program:
             del self.buffers[stem_out.buf]
             self.fused_away.add(stem_out.buf)
             layer = StemConv2Layer(stem_layer, name, weight, bias, act)
+            self.stems.remove(stem_layer)       # uploaded through the fused layer
             if out is None:
                 out = self.buffer(ho, wo, cout)
             assert (out.h, out.w, out.c) == (ho, wo, cout), (name, out, ho, wo, cout)
