@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the second NMS regime and the peak microbenchmarks (profiling runs: every launch of the "
                          "process then belongs to a full-batch step)")
+    ap.add_argument("--two-stream", action="store_true", help="NMS of step i on a second stream under step i+1's convs")
     ap.add_argument("--detail", default="", help="write the per-op timing table to this file")
     ap.add_argument("--backend", default="nccl", help="process-group backend for the barriers (gloo for CPU rehearsal)")
     ap.add_argument("--dry", action="store_true", help="no GPU work: rehearse the multi-rank protocol only")
@@ -238,9 +239,46 @@ class HostSink:
         return self.last_total
 
 
+class TwoStreamStep:
+    """One step with its NMS on a second stream: conv graph + decode of step i+1 (launch stream) run while NMS, row
+    packing and the copies of step i are still in flight.  Two decode / NMS arenas alternate, guarded by events."""
+
+    def __init__(self, model, device):
+        from yolo_amd.torch_utils import Arena
+        self.model = model
+        self.arenas = [Arena(), Arena()]
+        self.free = [None, None]
+        self.post = torch.cuda.Stream(device=device, priority=int(os.environ.get("YAMD_POST_PRIO", "0")))
+        self.n = 0
+
+    def __call__(self, images, sink):
+        k = self.n % 2
+        self.n += 1
+        m, arena = self.model, self.arenas[k]
+        cur = torch.cuda.current_stream()
+        raws = m.raw_heads(images)
+        if self.free[k] is not None:
+            cur.wait_event(self.free[k])          # the NMS that last read this arena's decoded tensor
+        pred = m.decode_predict(raws, arena)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(self.post):
+            self.post.wait_event(ready)
+            rows, counts = m.nms_predict(pred, arena)
+            sink.submit(rows, counts)
+            done = torch.cuda.Event()
+            done.record(self.post)
+            self.free[k] = done
+
+
 def step(model, images, sink):
+    if STEP_IMPL is not None:
+        return STEP_IMPL(images, sink)
     rows, counts = model.predict_device(images)
     sink.submit(rows, counts)
+
+
+STEP_IMPL = None
 
 
 def stage_profile(model, images, reps=3):
@@ -465,7 +503,14 @@ def main():
     A, width = rows0.shape[1], rows0.shape[2]
     sink = HostSink(B, A, width, dev)
     prog = model.program()
+    if args.two_stream:
+        global STEP_IMPL
+        STEP_IMPL = TwoStreamStep(model, dev)
 
+    if os.environ.get("YAMD_MAIN_PRIO"):
+        main_stream = torch.cuda.Stream(device=dev, priority=int(os.environ["YAMD_MAIN_PRIO"]))
+        main_stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(main_stream)
     for _ in range(args.warmup):
         step(model, images, sink)
     sink.drain()

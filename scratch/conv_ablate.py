@@ -11,6 +11,7 @@ stages = int(sys.argv[13]) if len(sys.argv) > 13 else 1
 tag = f"{k}{s}_{tw}_{mrep}{nrep}_{ck}_{nw}_{stages}"
 VARS = {"product": None, "no staging (barriers kept)": 1, "no MFMA": 2, "no staging, no barriers": 3}
 if len(sys.argv) > 13 and int(sys.argv[13]) == 2: VARS = {"product": None, "no MFMA": 2}
+if os.environ.get("ABLATE_EPI"): VARS = {"product": None, "no global stores": 4}
 if os.environ.get("ABLATE_TAG"):
     VARS = {"product": None}; tag += "_" + os.environ["ABLATE_TAG"]
 if os.environ.get("SKEW_BUILD") or os.environ.get("CONV_SKEW"):

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT)
 from yolo_amd import lib as L
 k, s, cin, cout, H, tw, mrep, nrep, ck = [int(v) for v in sys.argv[1:10]]
 nw, stages, B = [int(v) for v in sys.argv[10:13]] if len(sys.argv) > 12 else (4, 1, 256)
-so = os.path.join(ROOT, "scratch", f"libconv_trace_{k}{s}_{tw}_{mrep}{nrep}_{ck}" + (f"_{nw}_{stages}" if (nw, stages) != (4, 1) else "") + ".so")
+so = os.path.join(ROOT, "scratch", f"libconv_trace_{k}{s}_{tw}_{mrep}{nrep}_{ck}" + (f"_{nw}_{stages}" if (nw, stages) != (4, 1) else "") + os.environ.get("TRACE_TAG", "") + ".so")
 lib = ctypes.CDLL(so)
 d = L.ConvDesc()
 L.check(L.LIB.yamd_conv_desc_init(ctypes.byref(d), k, s, cin, cout, 1, 0))
@@ -22,7 +22,8 @@ wd, bd = wp.to(dev), bp.to(dev)
 trace = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
 grid = ctypes.c_int(0)
 lib.conv_trace_run.argtypes = [ctypes.c_void_p] * 1 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_void_p]
-for _ in range(3):
+for _ in range(int(os.environ.get("TRACE_RUNS", "3"))):
+    trace.zero_()
     rc = lib.conv_trace_run(x.data_ptr(), cin, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), cout, B, H, H, cin, cout, trace.data_ptr(), ctypes.byref(grid))
     assert rc == 0, L.LIB.yamd_last_error()
 torch.cuda.synchronize()
@@ -34,6 +35,13 @@ print(f"k{k}s{s} {cin}>{cout}@{Ho} blocks {len(t)}  total span {(t[:,4].max()-t[
 for i, n in enumerate(names):
     print(f"  {n:12s} mean {d_[:, i].mean():9.0f}  median {np.median(d_[:, i]):9.0f}  p90 {np.percentile(d_[:, i], 90):9.0f}")
 print(f"  block total  mean {(t[:,4]-t[:,0]).mean():9.0f}")
+span = float(t[:, 4].max() - t[:, 0].min())
+print(f"  mean concurrency (sum of block durations / span) {(t[:,4]-t[:,0]).sum() / span:7.1f} workgroups; blocks per slot {len(t) / ((t[:,4]-t[:,0]).sum() / span):6.1f}")
+if stages == 2:
+    print(f"  last epilogue (stamp 3 -> end) median {np.median(t[:,4]-t[:,3]):8.0f}  p90 {np.percentile(t[:,4]-t[:,3], 90):8.0f}")
+    order = np.argsort(t[:, 0]); st = t[order, 0]
+    print("  start times of the first 16 workgroups (ticks after the first):", (st[:16] - st[0]).tolist())
+    print("  starts, percentiles over all blocks:", [int(np.percentile(st - st[0], q)) for q in (10, 25, 50, 75, 90)])
 if t[:, 7].min() > 0:
     if stages == 1:
         print(f"  chunk 1: issue+MFMA {np.median(t[:,6]-t[:,5]):8.0f}   barrier+write+barrier {np.median(t[:,7]-t[:,6]):8.0f}")

@@ -61,9 +61,14 @@ struct ConvParams {
 };
 
 #ifdef YAMD_CONV_TRACE
+#ifdef YAMD_TRACE_REALTIME
+#define YAMD_TRACE_CLOCK __builtin_amdgcn_s_memrealtime      // constant 100 MHz, the same on every compute unit
+#else
+#define YAMD_TRACE_CLOCK __builtin_readcyclecounter          // shader clock of the workgroup's own XCD
+#endif
 #define YAMD_STAMP(i)                                                                              \
     do {                                                                                           \
-        if (threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0) p.trace[(size_t)blockIdx.x * 8 + (i)] = YAMD_TRACE_CLOCK();           \
     } while (0)
 #else
 #define YAMD_STAMP(i) \
@@ -154,9 +159,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
     if (bid >= p.total_tiles) return;
 #ifdef YAMD_CONV_SKEW
     if ((int)blockIdx.x < p.skew_blocks) {
-        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u;   // HW_ID.wave_id: this wave's slot on its SIMD
+        // experiment: first-round workgroups start late, by their wave slot on the SIMD (skew > 0: de-phases the workgroups that
+        // share a compute unit) or by their position in the dispatch order (skew < 0: de-phases the compute units)
+        const unsigned slot = p.skew > 0 ? (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 15u) : ((blockIdx.x >> 3) & 7u);
         const unsigned long long t0 = __builtin_readcyclecounter();
-        const unsigned long long wait = (unsigned long long)p.skew * slot;
+        const unsigned long long wait = (unsigned long long)abs(p.skew) * slot;
         while (__builtin_readcyclecounter() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
 #endif
@@ -517,7 +524,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
                     const char *row = wreg + (it * PIXPI + prow) * RSO;
                     const uint4 v = *(const uint4 *)(row + piece * 16);
                     const int spix = *(const int *)(row + NREP * 64);
+#if defined(YAMD_CONV_ABLATE) && YAMD_CONV_ABLATE == 4
+                    if (spix < -1 && sco_ok) *(uint4 *)(sdst + (size_t)spix * scs) = v;      // profiling build: nothing is stored
+#else
                     if (spix >= 0 && sco_ok) *(uint4 *)(sdst + (size_t)spix * scs) = v;
+#endif
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
@@ -606,6 +617,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
                 }
             }
             // the image just computed from is free; the other one already holds the next cout tile's first chunk
+#ifdef YAMD_CONV_TRACE
+            if (nt + 1 == p.n_tiles) YAMD_STAMP(3);
+#endif
             finish_tile(nt, smem + ((gi & 1) ^ 1) * stage_bytes);
             if (nt + 1 < p.n_tiles) __syncthreads();   // the next chunk stages into the image the epilogue used
         }
