@@ -299,6 +299,46 @@ int yamd_stem_conv2(int mode, const float *images, int batch, int h, int w, cons
                     int act2, void *y, int y_cstride, void *stream);
 
 /* ----------------------------------------------------------------------------------------
+ * A model's whole conv graph as one call.  Replaces `out5, out4, out3 = self.body_net(images)`, the module-by-module
+ * forward of the backbone + neck + head convs (yolov5/YoloV5.py:54 and :79 over yolov5/YoloV5Body.py:159-187,
+ * :223-260; the same statement in every other model class), for callers that do not want one foreign call per layer.
+ * A plan is a flat list of the entry points above with every argument resolved: ops[k].kind says which entry point,
+ * p[] / i[] hold its pointer / integer arguments in the slots listed beside each kind; batch and image size are the
+ * plan's, the image pointer and the stream are given per run.  The plan copies the list (and the conv descriptors in
+ * it); it owns no device memory: activation buffers and packed weights stay the caller's and must outlive it.
+ * yamd_plan_run only enqueues (one launch per op, in order, on `stream`) and stops at the first op that fails, whose
+ * index it stores to *failed_op (may be NULL; -1 on success).  One plan may be run from one host thread at a time.
+ * Pointer slots: p[0] input, p[1] packed weights, p[2] packed bias, p[3] residual or NULL, p[4] output (y / y1),
+ * p[5] second output (y2), p[6] third output (y3); for YAMD_OP_STEM_CONV2 p[5] / p[6] are the second conv's packed
+ * weights / bias.
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    YAMD_OP_CONV = 1,             /* yamd_conv2d_bias_act: desc; i = {x_cstride, res_cstride, y_cstride, h, w} */
+    YAMD_OP_CONV_SPLIT = 2,       /* yamd_conv2d_bias_act_split: desc; i = {x_cstride, -, y_cstride, h, w, y2_cstride, split_cout} */
+    YAMD_OP_STEM = 3,             /* yamd_stem_conv: i = {mode, cout, act, y_cstride} */
+    YAMD_OP_STEM_CONV2 = 4,       /* yamd_stem_conv2: i = {mode, c1, act1, y_cstride, c2, act2} */
+    YAMD_OP_FOCUS = 5,            /* yamd_focus_pack: i = {y_cstride} */
+    YAMD_OP_NHWC16 = 6,           /* yamd_nchw_to_nhwc16: i = {y_cstride, cin} */
+    YAMD_OP_UPSAMPLE2X = 7,       /* yamd_upsample2x: i = {x_cstride, y_cstride, h, w, c} */
+    YAMD_OP_MAXPOOL5_CASCADE = 8, /* yamd_maxpool5_cascade: i = {x_cstride, y_cstride, h, w, c} */
+    YAMD_OP_MAXPOOL3_CASCADE = 9, /* yamd_maxpool3_cascade: i = {x_cstride, y_cstride, h, w, c} */
+    YAMD_OP_MAXPOOL2 = 10,        /* yamd_maxpool2: i = {x_cstride, y_cstride, h, w, c} */
+    YAMD_OP_DEPTH_TO_SPACE2 = 11, /* yamd_depth_to_space2: i = {x_cstride, y_cstride, h, w, c (of the output)} */
+    YAMD_OP_COPY_CHANNELS = 12    /* yamd_copy_channels over batch*h*w pixels: i = {x_cstride, y_cstride, h, w, c} */
+};
+typedef struct yamd_plan_op {
+    int32_t kind;
+    int32_t i[8];
+    void *p[7];
+    yamd_conv_desc desc;          /* YAMD_OP_CONV / YAMD_OP_CONV_SPLIT only */
+} yamd_plan_op;
+typedef struct yamd_plan yamd_plan;
+int yamd_plan_create(const yamd_plan_op *ops, int n_ops, int batch, int img_h, int img_w, yamd_plan **plan_out);
+int yamd_plan_run(const yamd_plan *plan, const float *images, void *stream, int *failed_op);
+int yamd_plan_size(const yamd_plan *plan);      /* number of ops (0 for NULL) */
+void yamd_plan_destroy(yamd_plan *plan);
+
+/* ----------------------------------------------------------------------------------------
  * Measurement helpers for the benchmark's roofline denominators; no counterpart in the reference and not on the
  * detection path.
  *   yamd_microbench_mfma_bf16: `blocks` workgroups of 4 wavefronts, each wavefront issues 4*iters

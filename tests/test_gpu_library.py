@@ -157,3 +157,44 @@ def test_predict_device_captured_as_hip_graph(gpu_device):
             assert torch.equal(g_rows[b, :kb].view(torch.int32), rows[b, :kb].view(torch.int32))
         del graph
     assert sum(eager[0][1].cpu().tolist()) > 0
+
+
+def test_c_plan_replay_equals_per_op_calls(gpu_device):
+    """The conv graph replayed by one yamd_plan_run call (what Program.run does) and the same ops issued one foreign call
+    each from Python give bit-identical head logits, for an anchor model and an anchor-free one; a plan survives a
+    change of batch size (it is rebuilt) and reports the failing op by name."""
+    from yolo_amd import lib as L, models
+    from yolo_amd.init import seeded_images, seeded_state_dict
+    torch.cuda.set_device(gpu_device)
+    for name in ("v5s", "v8s", "v7pose"):
+        p, m = models.create(name, img_size=64)
+        m.load_state_dict(seeded_state_dict(m, seed=3, mode="spread", **models.init_options(name)))
+        prog = m.program()
+        for batch in (3, 1):
+            x = torch.from_numpy(seeded_images(batch, 64, seed=40 + batch)).to(gpu_device)
+            prog.use_c_plan = True
+            got = {k: v.clone() for k, v in prog.run(x).items()}
+            assert L.LIB.yamd_plan_size(prog.c_plan(batch, gpu_device).handle) == len(prog.ops)
+            prog.use_c_plan = False
+            want = prog.run(x)
+            prog.use_c_plan = True
+            assert set(got) == set(want)
+            for k in want:
+                assert torch.equal(got[k].view(torch.int32), want[k].view(torch.int32)), (name, batch, k)
+    # a plan whose op fails names it: an op with a bad pointer alignment is rejected by the entry point it calls
+    ops = (L.PlanOp * 1)()
+    ops[0].kind = L.OP_UPSAMPLE2X
+    for j, v in enumerate((16, 16, 4, 4, 16)):
+        ops[0].i[j] = v
+    buf = torch.zeros(1 << 16, dtype=torch.bfloat16, device=gpu_device)
+    ops[0].p[0] = buf.data_ptr() + 2          # not 16-byte aligned
+    ops[0].p[4] = buf.data_ptr() + 4096
+    import ctypes
+    h = ctypes.c_void_p()
+    assert L.LIB.yamd_plan_create(ops, 1, 1, 64, 64, ctypes.byref(h)) == 0
+    failed = ctypes.c_int(-7)
+    img = torch.zeros(1, 3, 64, 64, device=gpu_device)
+    assert L.LIB.yamd_plan_run(h, img.data_ptr(), L.current_stream(), ctypes.byref(failed)) != 0 and failed.value == 0
+    L.LIB.yamd_plan_destroy(h)
+    ops[0].kind = 99
+    assert L.LIB.yamd_plan_create(ops, 1, 1, 64, 64, ctypes.byref(h)) != 0

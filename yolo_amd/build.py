@@ -30,6 +30,7 @@ SOURCES = [
     ("yamd_metric.hip", ["-ffp-contract=off"]),
     ("yamd_stem.hip", []),
     ("yamd_microbench.hip", []),
+    ("yamd_plan.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
 HEADERS = [os.path.join(CSRC, "yamd_common.h"), os.path.join(CSRC, "yamd_conv_kernel.h"),

@@ -29,6 +29,32 @@ class View(NamedTuple):
         return View(self.buf, self.coff + coff, c, self.h, self.w)
 
 
+_PACK_GENERATION = [0]      # bumped whenever a layer's packed weights or descriptor change: compiled C plans are stale then
+
+
+class _CPlan:
+    """Owner of a ``yamd_plan`` handle (the recorded program with every argument resolved, replayed by one C call)."""
+
+    def __init__(self, ops: "ctypes.Array", batch: int, img_h: int, img_w: int, names: List[str], keep: tuple):
+        self.handle = ctypes.c_void_p()
+        _lib.check(LIB.yamd_plan_create(ops, len(ops), batch, img_h, img_w, ctypes.byref(self.handle)), "plan_create")
+        self.names = names
+        self.keep = keep              # the tensors whose addresses the plan holds
+        self.generation = _PACK_GENERATION[0]
+        self.failed = ctypes.c_int(-1)
+
+    def run(self, images_ptr: int, stream: int) -> None:
+        rc = LIB.yamd_plan_run(self.handle, images_ptr, stream, ctypes.byref(self.failed))
+        if rc != 0:
+            k = self.failed.value
+            _lib.check(rc, self.names[k] if 0 <= k < len(self.names) else "plan_run")
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            LIB.yamd_plan_destroy(self.handle)
+            self.handle = None
+
+
 class ConvLayer:
     """One fused conv: descriptor + packed weights (host copies kept so any device can be fed)."""
 
@@ -66,6 +92,7 @@ class ConvLayer:
         self.w_host, self.b_host = wp, bp
         self.w_dev: Optional[torch.Tensor] = None
         self.b_dev: Optional[torch.Tensor] = None
+        _PACK_GENERATION[0] += 1
 
     @property
     def tiling(self) -> Tuple[int, int, int, int, int]:
@@ -150,6 +177,8 @@ class Program:
         self.taps: Dict[str, View] = {}                 # named intermediate activations (verification aid, see read_view)
         self.alias: Dict[str, Tuple[str, int]] = {}     # buffer -> (wider buffer it lives in, first channel)
         self._alloc: Dict[Tuple[int, str], Dict[str, torch.Tensor]] = {}
+        self._cplan: Dict[Tuple[int, str], _CPlan] = {}
+        self.use_c_plan = True                   # False: run() issues one foreign call per op from Python (same calls, same order)
         self._n = 0
         self.span_sink: Optional[list] = None    # when set, every run() appends its conv spans here (see run)
         self.fused_away: set = set()             # buffers whose producer was merged into its consumer: never written
@@ -488,6 +517,7 @@ class Program:
         key = (batch, str(device))
         if key not in self._alloc:
             self._alloc.clear()   # one live batch size at a time: the arena is large
+            self._cplan.clear()
             self._alloc[key] = {n: torch.empty((batch, h, w, c), dtype=dt, device=device)
                                 for n, (h, w, c, dt) in self.buffers.items() if n not in self.alias}
             for layer in self.convs + self.stems:
@@ -498,6 +528,86 @@ class Program:
         buf, coff = self.resolve(v)
         t = bufs[buf]
         return t.data_ptr() + coff * t.element_size(), t.shape[-1]
+
+    def c_plan(self, batch: int, device) -> _CPlan:
+        """The recorded ops as a ``yamd_plan`` for this batch size and device (built once; rebuilt when a layer was
+        re-packed or the buffers were re-allocated)."""
+        key = (batch, str(device))
+        plan = self._cplan.get(key)
+        if plan is not None and plan.generation == _PACK_GENERATION[0]:
+            return plan
+        bufs = self._buffers_for(batch, device)
+        for layer in self.convs + self.stems:
+            layer.to(device)
+        P = self._ptr
+        ops = (_lib.PlanOp * len(self.ops))()
+        names: List[str] = []
+        for o, op in zip(ops, self.ops):
+            kind = op[0]
+
+            def fill(k, ints, ptrs):
+                o.kind = k
+                for j, v in enumerate(ints):
+                    o.i[j] = int(v)
+                for j, v in ptrs.items():
+                    o.p[j] = v
+
+            if kind == "conv":
+                _, layer, x, out, res, out2 = op
+                xp, xcs = P(bufs, x)
+                yp, ycs = P(bufs, out)
+                o.desc = layer.desc
+                if out2 is not None:
+                    y2p, y2cs = P(bufs, out2)
+                    fill(_lib.OP_CONV_SPLIT, (xcs, 0, ycs, x.h, x.w, y2cs, out.c),
+                         {0: xp, 1: layer.w_dev.data_ptr(), 2: layer.b_dev.data_ptr(), 4: yp, 5: y2p})
+                else:
+                    rp, rcs = P(bufs, res) if res is not None else (None, 0)
+                    fill(_lib.OP_CONV, (xcs, rcs, ycs, x.h, x.w),
+                         {0: xp, 1: layer.w_dev.data_ptr(), 2: layer.b_dev.data_ptr(), 3: rp, 4: yp})
+                names.append(f"conv[{layer.name}]")
+            elif kind == "stem":
+                _, layer, out = op
+                yp, ycs = P(bufs, out)
+                fill(_lib.OP_STEM, (layer.mode, layer.cout, layer.act, ycs),
+                     {1: layer.w_dev.data_ptr(), 2: layer.b_dev.data_ptr(), 4: yp})
+                names.append(f"stem[{layer.name}]")
+            elif kind == "stem2":
+                _, layer, out = op
+                yp, ycs = P(bufs, out)
+                st1 = layer.stem
+                fill(_lib.OP_STEM_CONV2, (st1.mode, st1.cout, st1.act, ycs, layer.cout, layer.act),
+                     {1: st1.w_dev.data_ptr(), 2: st1.b_dev.data_ptr(), 4: yp, 5: layer.w_dev.data_ptr(), 6: layer.b_dev.data_ptr()})
+                names.append(f"stem_conv2[{layer.name}]")
+            elif kind == "focus":
+                yp, ycs = P(bufs, op[1])
+                fill(_lib.OP_FOCUS, (ycs,), {4: yp})
+                names.append("focus")
+            elif kind == "nhwc16":
+                yp, ycs = P(bufs, op[1])
+                fill(_lib.OP_NHWC16, (ycs, op[2]), {4: yp})
+                names.append("nhwc16")
+            elif kind == "mp5":
+                _, x, y1, y2, y3, kernel = op
+                xp, xcs = P(bufs, x)
+                p1, ycs = P(bufs, y1)
+                fill(_lib.OP_MAXPOOL5_CASCADE if kernel == 5 else _lib.OP_MAXPOOL3_CASCADE, (xcs, ycs, x.h, x.w, x.c),
+                     {0: xp, 4: p1, 5: P(bufs, y2)[0], 6: P(bufs, y3)[0]})
+                names.append("maxpool_cascade")
+            elif kind in ("up2", "copy", "d2s", "mp2"):
+                _, x, out = op
+                xp, xcs = P(bufs, x)
+                yp, ycs = P(bufs, out)
+                code = {"up2": _lib.OP_UPSAMPLE2X, "copy": _lib.OP_COPY_CHANNELS, "d2s": _lib.OP_DEPTH_TO_SPACE2,
+                        "mp2": _lib.OP_MAXPOOL2}[kind]
+                fill(code, (xcs, ycs, x.h, x.w, out.c if kind == "d2s" else x.c), {0: xp, 4: yp})
+                names.append(kind)
+            else:
+                raise AssertionError(kind)
+        keep = tuple(bufs.values()) + tuple(t for layer in self.convs + self.stems for t in (layer.w_dev, layer.b_dev))
+        plan = _CPlan(ops, batch, self.img_h, self.img_w, names, keep)
+        self._cplan[key] = plan
+        return plan
 
     def run(self, images: torch.Tensor, timings: Optional[list] = None, conv_spans: Optional[list] = None
             ) -> Dict[str, torch.Tensor]:
@@ -520,6 +630,10 @@ class Program:
         span_open = None
         if conv_spans is None:
             conv_spans = self.span_sink
+        if timings is None and conv_spans is None and self.use_c_plan:
+            # the usual case: the whole list replayed by one C call (arguments were resolved when the plan was made)
+            self.c_plan(B, images.device).run(images.data_ptr(), st)
+            return self._outputs(bufs)
         for op in self.ops:
             kind = op[0]
             if conv_spans is not None:
@@ -608,6 +722,9 @@ class Program:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             conv_spans.append((span_open, ev))
+        return self._outputs(bufs)
+
+    def _outputs(self, bufs: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         res = {}
         for name, v in self.outputs.items():
             buf, coff = self.resolve(v)

@@ -22,7 +22,12 @@ EXPORTS = [
     "yamd_copy_channels", "yamd_depth_to_space2", "yamd_decode_ltrb_points",
     "yamd_decode_anchor", "yamd_decode_anchor_levels", "yamd_decode_dfl", "yamd_decode_dfl_unit_conf", "yamd_decode_dfl_points", "yamd_nms_workspace_bytes", "yamd_nms_batched", "yamd_nms_static_capacity_bytes", "yamd_nms_batched_static", "yamd_compact_rows", "yamd_letterbox_workspace_bytes", "yamd_letterbox_u8", "yamd_detect_match", "yamd_stem_packed_elems", "yamd_stem_pack_weights", "yamd_stem_conv", "yamd_stem_conv2_packed_elems", "yamd_stem_conv2_pack_weights", "yamd_stem_conv2",
     "yamd_microbench_mfma_bf16", "yamd_microbench_copy",
+    "yamd_plan_create", "yamd_plan_run", "yamd_plan_size", "yamd_plan_destroy",
 ]
+
+# yamd_plan_op.kind
+OP_CONV, OP_CONV_SPLIT, OP_STEM, OP_STEM_CONV2, OP_FOCUS, OP_NHWC16, OP_UPSAMPLE2X, OP_MAXPOOL5_CASCADE, \
+    OP_MAXPOOL3_CASCADE, OP_MAXPOOL2, OP_DEPTH_TO_SPACE2, OP_COPY_CHANNELS = range(1, 13)
 
 
 class ConvDesc(ctypes.Structure):
@@ -30,6 +35,11 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [("ksize", c_int32), ("stride", c_int32), ("cin", c_int32), ("cout", c_int32), ("act", c_int32),
                 ("out_f32", c_int32), ("nrep", c_int32), ("ck", c_int32), ("mrep", c_int32), ("cout_pad", c_int32),
                 ("packed_w_elems", c_int64), ("nwaves", c_int32), ("residual_scale", ctypes.c_float), ("stages", c_int32)]
+
+
+class PlanOp(ctypes.Structure):
+    """Mirror of ``yamd_plan_op``."""
+    _fields_ = [("kind", c_int32), ("i", c_int32 * 8), ("p", c_void_p * 7), ("desc", ConvDesc)]
 
 
 class YamdError(RuntimeError):
@@ -103,9 +113,14 @@ def _load() -> ctypes.CDLL:
     lib.yamd_nms_static_capacity_bytes.argtypes = []
     lib.yamd_nms_batched_static.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_double,
                                             c_void_p, c_void_p, c_int, c_void_p, c_void_p]
+    lib.yamd_plan_create.argtypes = [P(PlanOp), c_int, c_int, c_int, c_int, P(c_void_p)]
+    lib.yamd_plan_run.argtypes = [c_void_p, c_void_p, c_void_p, P(c_int)]
+    lib.yamd_plan_size.argtypes = [c_void_p]
+    lib.yamd_plan_destroy.argtypes = [c_void_p]
+    lib.yamd_plan_destroy.restype = None
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("yamd_last_error", "yamd_nms_workspace_bytes", "yamd_letterbox_workspace_bytes", "yamd_stem_packed_elems", "yamd_stem_conv2_packed_elems",
+        if name not in ("yamd_plan_destroy","yamd_last_error", "yamd_nms_workspace_bytes", "yamd_letterbox_workspace_bytes", "yamd_stem_packed_elems", "yamd_stem_conv2_packed_elems",
                         "yamd_nms_static_capacity_bytes"):
             fn.restype = c_int
     return lib
