@@ -414,6 +414,44 @@ def measured_peaks(dev):
                                                 2.0 * nbytes / (t * 1e-3) / 1e9) for v, t in variants.items())}
 
 
+def sustained_clock(load, dev, min_ms: float = 30.0):
+    """Shader clock (GHz) the device holds while ``load()`` keeps the launch stream busy: a one-wavefront probe on a
+    second stream samples the shader clock counter against the constant-rate counter (calibrated here against the
+    probe's own event time).  Median over the samples taken while the load was running."""
+    from yolo_amd import lib as L
+    n, naps = 2000, 3
+    samples = torch.zeros(2 * n, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    load()
+    torch.cuda.synchronize()
+    m0.record()
+    load()
+    m1.record()
+    torch.cuda.synchronize()
+    load_ms = m0.elapsed_time(m1)
+    reps = max(2, int(np.ceil(min_ms * 1.6 / max(load_ms, 1e-3))))     # the probe takes about min_ms; the load outlasts it
+    load()
+    with torch.cuda.stream(side):
+        e0.record(side)
+        L.check(L.LIB.yamd_microbench_clock_probe(samples.data_ptr(), n, naps, int(side.cuda_stream)))
+        e1.record(side)
+    for _ in range(reps):
+        load()
+    torch.cuda.synchronize()
+    s = samples.cpu().numpy().reshape(n, 2).astype(np.float64)
+    probe_ms = e0.elapsed_time(e1)
+    tick_hz = (s[-1, 1] - s[0, 1]) / (probe_ms * 1e-3)            # rate of the constant counter, measured
+    dc, dr = np.diff(s[:, 0]), np.diff(s[:, 1])
+    ghz = dc / np.maximum(dr, 1.0) * tick_hz / 1e9
+    keep = ghz[n // 10: -n // 10]
+    return {"GHz": round(float(np.median(keep)), 3), "p10": round(float(np.percentile(keep, 10)), 3),
+            "p90": round(float(np.percentile(keep, 90)), 3), "probe_ms": round(probe_ms, 2),
+            "constant_counter_MHz": round(tick_hz / 1e6, 2), "load_repetitions": reps + 1,
+            "load_ms_each": round(load_ms, 3)}
+
+
 def measured_conv_traffic(model_name: str, batch: int, n_conv: int):
     """HBM bytes per conv launch from the committed PMC passes (profiles/*_conv_hbm_traffic.json, written by
     scratch/pmc_conv.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command): counters cannot be
@@ -581,6 +619,18 @@ def main():
         if not args.no_extras:
             peaks = measured_peaks(dev)
             out["measured_peaks"] = peaks
+            # the shader clock the device holds under its power limit, for the two loads the roofline compares
+            ops = (torch.rand(4096, device=dev) * 2 - 1).to(torch.bfloat16)
+            msink = torch.empty(512 * 256, dtype=torch.float32, device=dev)
+            clk_conv = sustained_clock(lambda: prog.run(images), dev)
+            clk_mfma = sustained_clock(lambda: L.check(L.LIB.yamd_microbench_mfma_bf16(ops.data_ptr(), msink.data_ptr(), 512, 4096,
+                                                                                        L.current_stream())), dev)
+            peaks["shader_clock"] = {"conv_program": clk_conv, "mfma_loop": clk_mfma, "nominal_GHz": 2.4,
+                                     "note": "one-wavefront probe on a second stream while the load runs; the device runs "
+                                             "at its socket power limit under both loads, below the 2.4 GHz the nominal "
+                                             "MFMA peak assumes"}
+            out["roofline"]["peak_at_sustained_clock"] = round(PEAK_BF16_TFLOPS * clk_conv["GHz"] / 2.4, 1)
+            out["roofline"]["frac_at_sustained_clock"] = round(conv_tflops / (PEAK_BF16_TFLOPS * clk_conv["GHz"] / 2.4), 4)
             out["roofline"]["frac_of_measured_mfma_loop"] = round(conv_tflops / peaks["mfma_bf16_TFLOPs"], 4)
             out["decode_hbm"]["frac_of_measured_copy"] = round(out["decode_hbm"]["achieved_GBs"] / peaks["hbm_copy_GBs"], 4)
             if args.model == "v5s" and world == 1:

@@ -350,6 +350,11 @@ void yamd_plan_destroy(yamd_plan *plan);
  * ---------------------------------------------------------------------------------------- */
 int yamd_microbench_mfma_bf16(const void *operands, float *sink, int blocks, int iters, void *stream);
 int yamd_microbench_copy(const void *src, void *dst, size_t bytes, int variant, void *stream);
+/*   yamd_microbench_clock_probe: one wavefront writes n_samples pairs (shader clock counter of its XCD, constant-rate
+ *       counter) to `samples` (2*n_samples uint64, device), sleeping naps * 127 * 64 cycles between pairs; launched on a
+ *       second stream it records the shader clock the device holds under the load of the first.  n_samples <= 65536,
+ *       naps <= 64: the kernel always ends by itself. */
+int yamd_microbench_clock_probe(unsigned long long *samples, int n_samples, int naps, void *stream);
 
 #ifdef __cplusplus
 }

@@ -52,7 +52,28 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const u32x4 *__restric
     }
 }
 
+// One lane samples the shader clock counter of its XCD and the constant-rate counter, then sleeps, n times: the ratio of
+// the two differences is the shader clock the device holds while other streams keep it busy.  Bounded: the kernel ends
+// after n * naps sleeps of 127 * 64 cycles.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long *samples, int n, int naps)
+{
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < n; ++i) {
+        samples[2 * i] = __builtin_readcyclecounter();
+        samples[2 * i + 1] = __builtin_amdgcn_s_memrealtime();
+        for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+}
+
 }  // namespace
+
+extern "C" int yamd_microbench_clock_probe(unsigned long long *samples, int n_samples, int naps, void *stream)
+{
+    YAMD_REQUIRE(samples && n_samples > 0 && n_samples <= (1 << 16) && naps > 0 && naps <= 64, "bad argument");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, samples, n_samples, naps);
+    YAMD_LAUNCH_CHECK();
+    return YAMD_OK;
+}
 
 extern "C" int yamd_microbench_mfma_bf16(const void *operands, float *sink, int blocks, int iters, void *stream)
 {

@@ -21,7 +21,7 @@ EXPORTS = [
     "yamd_focus_pack", "yamd_nchw_to_nhwc16", "yamd_upsample2x", "yamd_maxpool2", "yamd_maxpool5_cascade", "yamd_maxpool3_cascade",
     "yamd_copy_channels", "yamd_depth_to_space2", "yamd_decode_ltrb_points",
     "yamd_decode_anchor", "yamd_decode_anchor_levels", "yamd_decode_dfl", "yamd_decode_dfl_unit_conf", "yamd_decode_dfl_points", "yamd_nms_workspace_bytes", "yamd_nms_batched", "yamd_nms_static_capacity_bytes", "yamd_nms_batched_static", "yamd_compact_rows", "yamd_letterbox_workspace_bytes", "yamd_letterbox_u8", "yamd_detect_match", "yamd_stem_packed_elems", "yamd_stem_pack_weights", "yamd_stem_conv", "yamd_stem_conv2_packed_elems", "yamd_stem_conv2_pack_weights", "yamd_stem_conv2",
-    "yamd_microbench_mfma_bf16", "yamd_microbench_copy",
+    "yamd_microbench_mfma_bf16", "yamd_microbench_copy", "yamd_microbench_clock_probe",
     "yamd_plan_create", "yamd_plan_run", "yamd_plan_size", "yamd_plan_destroy",
 ]
 
@@ -100,6 +100,7 @@ def _load() -> ctypes.CDLL:
                                     c_int, c_int, c_void_p, c_int, c_void_p]
     lib.yamd_microbench_mfma_bf16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.yamd_microbench_copy.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_void_p]
+    lib.yamd_microbench_clock_probe.argtypes = [c_void_p, c_int, c_int, c_void_p]
     lib.yamd_letterbox_workspace_bytes.restype = c_size_t
     lib.yamd_letterbox_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.yamd_letterbox_u8.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
