@@ -117,7 +117,7 @@ int yamd_upsample2x(const void *x, int x_cstride, void *y, int y_cstride, int ba
 /* Three cascaded 5x5 stride-1 max-pools with -inf padding: y1 = mp5(x), y2 = mp5(y1), y3 = mp5(y2),
  * i.e. the k=5,9,13 pools of SPP (yolov5/YoloV5Body.py:114-132, yolov4/YoloV4BackBone.py:151-162)
  * and the serial pools of SPPF (yolov8/YoloV8Body.py:102-114).  All four tensors are channel slices
- * (c % 8 == 0) and may live in the same concat buffer. h*w <= 1024. */
+ * (c % 8 == 0) and may live in the same concat buffer. h*w <= 4096. */
 int yamd_maxpool5_cascade(const void *x, int x_cstride, void *y1, void *y2, void *y3, int y_cstride,
                           int batch, int h, int w, int c, void *stream);
 /* The same with 3x3 pools: y1 = mp3(x), y2 = mp3(y1), y3 = mp3(y2), i.e. the k=3,5,7 pools of the face / pose
