@@ -283,13 +283,16 @@ int yamd_stem_conv(int mode, const float *images, int batch, int h, int w, const
                    const float *bias_packed, int cout, int act, void *y, int y_cstride, void *stream);
 
 /* ----------------------------------------------------------------------------------------
- * The first two layers of a backbone in one launch: a stride-2 stem (YAMD_STEM_FOCUS or YAMD_STEM_K3S2, as above)
- * followed by Conv2d(c1, c2, 3, 2, 1) + bias + act, i.e. `x = self.stem(x)` and the first module of `self.dark2`
- * (yolov5/YoloV5Body.py:139-141,160-161, yolov8/YoloV8Body.py:124-126,143-144).  Same result as yamd_stem_conv into a
+ * The first two layers of a backbone in one launch: a stem (YAMD_STEM_FOCUS or YAMD_STEM_K3S2 as above, or
+ * YAMD_STEM_K3S1 with c1 = 32) followed by Conv2d(c1, c2, 3, 2, 1) + bias + act, i.e. `x = self.stem(x)` and the first
+ * module of `self.dark2` (yolov5/YoloV5Body.py:139-141,160-161, yolov8/YoloV8Body.py:124-126,143-144), `conv1` and the
+ * down-sampling conv of `layer_1` (yolov3/DarkNet53.py:58-62,73-76), the first two convs of CSPDarkNet and of the v7
+ * backbone (yolov4/YoloV4BackBone.py, yolov7_pose/YoloV7PoseBody.py).  Same result as yamd_stem_conv into a
  * (batch, h/2, w/2, c1) bf16 tensor followed by yamd_conv2d_bias_act on it (the intermediate is rounded to bf16 in
  * both), but that tensor, the largest activation of the network, is never written to memory.
- * c1 = 32 or 64 (the stem's cout); c2 a multiple of 8, at most 128 for c1 = 32 and 64 for c1 = 64.
- * w2: (c2, c1, 3, 3) fp32 with BN folded, packed on the host; bias_packed: 128 floats.  y: (batch, h/4, w/4, *) bf16.
+ * c1 = 32 or 64 (the stem's cout); c2 a multiple of 8, at most 128 for c1 = 32 and 64 for c1 = 64; h and w even.
+ * w2: (c2, c1, 3, 3) fp32 with BN folded, packed on the host; bias_packed: 128 floats.  y: (batch, h/4, w/4, *) bf16 after
+ * a stride-2 stem, (batch, h/2, w/2, *) after a stride-1 stem.
  * ---------------------------------------------------------------------------------------- */
 int64_t yamd_stem_conv2_packed_elems(int c1, int c2);   /* bf16 elements of the second conv's packed weights; 0 = unsupported */
 int yamd_stem_conv2_pack_weights(const float *w2_host, const float *bias2_host, int c1, int c2, void *w2_packed_host,

@@ -429,6 +429,10 @@ def test_conv_split_output(gpu_device, k, s, cin, cout, split, H, W):
     ("k3s2", 32, 40, 52, 36, 1, 0),        # second conv's last cout fragment partly filled, no activation
     ("focus", 64, 64, 44, 68, 1, 3),       # 64-channel stem output (4 k-steps per tap)
     ("k3s2", 64, 24, 36, 40, 4, 1),        # a single cout fragment: half of the wavefronts have no second-conv work
+    ("k3s1", 32, 64, 38, 76, 2, 2),        # the stride-1 stems: DarkNet53 (LeakyReLU), CSPDarkNet (Mish), v7 (SiLU)
+    ("k3s1", 32, 64, 64, 32, 3, 3),
+    ("k3s1", 32, 64, 20, 44, 1, 1),
+    ("k3s1", 32, 104, 18, 34, 1, 4),
 ])
 def test_stem_and_next_conv_fused(gpu_device, mode, c1, c2, H, W, act1, act2):
     """yamd_stem_conv2 against torch: stem from the fp32 image, its output rounded to bf16 (what the unfused path
@@ -448,11 +452,11 @@ def test_stem_and_next_conv_fused(gpu_device, mode, c1, c2, H, W, act1, act2):
         xf = torch.cat((xb[..., ::2, ::2], xb[..., 1::2, ::2], xb[..., ::2, 1::2], xb[..., 1::2, 1::2]), 1)
         mid = F.conv2d(xf, w1, b1, stride=1, padding=1)
     else:
-        mid = F.conv2d(xb, w1, b1, stride=2, padding=1)
+        mid = F.conv2d(xb, w1, b1, stride=1 if mode == "k3s1" else 2, padding=1)
     mid = _bf16_round(_act(mid, act1))
     want = _act(F.conv2d(mid, w2, b2, stride=2, padding=1), act2)
     stem = StemLayer("t", mode, w1, b1, act1)
-    assert StemConv2Layer.supported(stem, c2)
+    assert StemConv2Layer.supported(stem, c2) == (mode != "k3s1")      # the plan fuses stride-2 stems only (the library takes both)
     layer = StemConv2Layer(stem, "t2", w2, b2, act2)
     layer.to(gpu_device)
     Ho, Wo = want.shape[2], want.shape[3]
@@ -471,9 +475,11 @@ def test_stem_and_next_conv_fused(gpu_device, mode, c1, c2, H, W, act1, act2):
     assert float(err.abs().max()) <= 3e-2 * float(want.abs().max())
     # shapes the fused form does not take are refused, not mis-computed
     assert L.LIB.yamd_stem_conv2_packed_elems(48, 96) == 0 and L.LIB.yamd_stem_conv2_packed_elems(64, 128) == 0
-    assert L.LIB.yamd_stem_conv2(0, xd.data_ptr(), Bn, H, W, stem.w_dev.data_ptr(), stem.b_dev.data_ptr(), c1, act1,
-                                 layer.w_dev.data_ptr(), layer.b_dev.data_ptr(), c2, act2, y.data_ptr(), y.shape[-1],
-                                 L.current_stream()) != 0
+    # (a stride-1 stem with 64 channels, an unknown mode, an odd image)
+    for bad_mode, bad_c1, bad_h in ((0, 64, H), (7, c1, H), (stem.mode, c1, H + 1)):
+        assert L.LIB.yamd_stem_conv2(bad_mode, xd.data_ptr(), Bn, bad_h, W, stem.w_dev.data_ptr(), stem.b_dev.data_ptr(), bad_c1,
+                                     act1, layer.w_dev.data_ptr(), layer.b_dev.data_ptr(), c2 if bad_c1 == c1 else 64, act2,
+                                     y.data_ptr(), y.shape[-1], L.current_stream()) != 0
 
 
 @pytest.mark.parametrize("mode,cout,H,W,act", [("k3s1", 32, 40, 72, 1), ("k3s1", 64, 33, 35, 2), ("k3s2", 32, 64, 96, 1),

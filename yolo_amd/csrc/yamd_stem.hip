@@ -171,7 +171,8 @@ int launch_stem(const StemParams &p, int batch, hipStream_t st)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The first TWO convs of a backbone in one kernel: the stem above, then a 3x3 stride-2 conv (pad 1) on its output.
+// The first TWO convs of a backbone in one kernel: the stem above (stride 2, or 3x3 stride 1 with 32 output channels), then
+// a 3x3 stride-2 conv (pad 1) on its output.
 // The stem's output (the largest activation of the network) is never written to memory: a workgroup computes the
 // stem on the (2*4+1) x (2*16+1) pixels that its 4 x 16 tile of the second conv needs, keeps them in LDS as bf16 (the
 // same rounding the unfused path applies when it stores them) and runs the second conv from there.  Pixels of that
@@ -572,7 +573,8 @@ extern "C" int yamd_stem_conv2(int mode, const float *images, int batch, int h, 
 {
     YAMD_REQUIRE(images && w1_packed && b1_packed && w2_packed && b2_packed && y, "null argument");
     int ks, s;
-    YAMD_REQUIRE(stem_mode(mode, ks, s) && s == 2, "the fused form takes a stride-2 stem (mode %d)", mode);
+    YAMD_REQUIRE(stem_mode(mode, ks, s), "unknown stem mode %d", mode);
+    YAMD_REQUIRE(s == 2 || c1 == 32, "the fused form takes a stride-1 stem with 32 output channels only (got %d)", c1);
     YAMD_REQUIRE(batch > 0 && h > 0 && w > 0 && h % 2 == 0 && w % 2 == 0, "bad image shape %dx%dx%d", batch, h, w);
     YAMD_REQUIRE(yamd_stem_conv2_packed_elems(c1, c2) > 0, "fused second conv: cin=%d (32 or 64), cout=%d (multiple of 8; <= 128 for cin 32, <= 64 for cin 64)", c1, c2);
     YAMD_REQUIRE(act1 >= YAMD_ACT_NONE && act1 <= YAMD_ACT_RELU && act2 >= YAMD_ACT_NONE && act2 <= YAMD_ACT_RELU, "unknown activation");
@@ -589,8 +591,8 @@ extern "C" int yamd_stem_conv2(int mode, const float *images, int batch, int h, 
     p.H = h;
     p.W = w;
     const int pad = ks == 6 ? 2 : 1;
-    p.H1 = (h + 2 * pad - ks) / 2 + 1;
-    p.W1 = (w + 2 * pad - ks) / 2 + 1;
+    p.H1 = (h + 2 * pad - ks) / s + 1;
+    p.W1 = (w + 2 * pad - ks) / s + 1;
     p.H2 = (p.H1 - 1) / 2 + 1;
     p.W2 = (p.W1 - 1) / 2 + 1;
     p.C2 = c2;
@@ -606,6 +608,14 @@ extern "C" int yamd_stem_conv2(int mode, const float *images, int batch, int h, 
     p.total_tiles = (int)total;
     hipStream_t st = (hipStream_t)stream;
     const int nrep2 = (c2 + 31) / 32;
+    if (s == 1) {
+        switch (nrep2) {
+        case 1: return launch_stem_conv2<3, 1, 1, 1>(p, st);
+        case 2: return launch_stem_conv2<3, 1, 1, 2>(p, st);
+        case 3: return launch_stem_conv2<3, 1, 1, 3>(p, st);
+        default: return launch_stem_conv2<3, 1, 1, 4>(p, st);
+        }
+    }
     if (c1 == 32) {
         switch (nrep2 * 10 + (ks == 6)) {
         case 11: return launch_stem_conv2<6, 2, 1, 1>(p, st);

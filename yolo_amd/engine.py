@@ -133,8 +133,8 @@ class StemLayer:
 
 
 class StemConv2Layer:
-    """A stride-2 stem and the 3x3 stride-2 conv that follows it, run as one launch (``yamd_stem_conv2``): the stem's
-    output is never written to memory."""
+    """A stem (stride 2, or 3x3 stride 1 with 32 output channels) and the 3x3 stride-2 conv that follows it, run as one
+    launch (``yamd_stem_conv2``): the stem's output is never written to memory."""
 
     def __init__(self, stem: StemLayer, name: str, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int):
         w = weight.detach().to(torch.float32).cpu().contiguous()
@@ -156,6 +156,9 @@ class StemConv2Layer:
 
     @staticmethod
     def supported(stem: StemLayer, cout: int) -> bool:
+        # (the library also takes a 3x3 stride-1 stem with 32 channels; measured slower than the two separate kernels at
+        # 608 x 608 -- v3 conv stage 50.2 against 47.0 ms -- because its 4 x 16 output tiles are too small for a second conv
+        # that runs at half the image resolution, so the plan does not select it)
         return stem.mode in (StemLayer.MODES["k3s2"], StemLayer.MODES["focus"]) and \
             LIB.yamd_stem_conv2_packed_elems(stem.cout, cout) > 0
 
@@ -229,7 +232,7 @@ class Program:
             return out
         if (self.ops and self.ops[-1][0] == "stem" and self.ops[-1][2] == x and k == 3 and stride == 2 and residual is None
                 and out2 is None and not out_f32 and StemConv2Layer.supported(self.ops[-1][1], cout)
-                and not os.environ.get("YAMD_NO_STEM_FUSION")):
+                and self.img_h % 2 == 0 and self.img_w % 2 == 0 and not os.environ.get("YAMD_NO_STEM_FUSION")):
             # the stem's only reader follows it directly: both run as one launch and the stem's output, the largest
             # activation of the network, is never written (a later reader of that buffer would find it unwritten, so the
             # buffer is dropped: recording such a reader fails in resolve())
@@ -466,7 +469,8 @@ class Program:
             elif op[0] == "stem":
                 total += op[1].macs_per_pixel * op[2].h * op[2].w
             elif op[0] == "stem2":      # the MACs of the two layers, not of the fused kernel (which recomputes tile overlaps)
-                total += op[1].macs_per_pixel * op[2].h * op[2].w + op[1].stem.macs_per_pixel * (self.img_h // 2) * (self.img_w // 2)
+                sdiv = 1 if op[1].stem.mode == StemLayer.MODES["k3s1"] else 2
+                total += op[1].macs_per_pixel * op[2].h * op[2].w + op[1].stem.macs_per_pixel * (self.img_h // sdiv) * (self.img_w // sdiv)
         return total
 
     def activation_bytes_per_image(self) -> int:
@@ -494,7 +498,8 @@ class Program:
         if kind == "stem2":
             _, layer, out = op
             px = batch * out.h * out.w
-            flops = 2.0 * layer.macs_per_pixel * px + 2.0 * layer.stem.macs_per_pixel * batch * (self.img_h // 2) * (self.img_w // 2)
+            sdiv = 1 if layer.stem.mode == StemLayer.MODES["k3s1"] else 2
+            flops = 2.0 * layer.macs_per_pixel * px + 2.0 * layer.stem.macs_per_pixel * batch * (self.img_h // sdiv) * (self.img_w // sdiv)
             return flops, float(batch * self.img_h * self.img_w * 3 * 4 + px * out.c * 2 + layer.macs_per_pixel * 2)
         if kind == "focus":
             return 0.0, float(batch * self.img_h * self.img_w * 3 * 4 + batch * op[1].h * op[1].w * 16 * 2)
