@@ -161,8 +161,9 @@ def test_v5s_layer_by_layer_vs_oracle(gpu_device, monkeypatch):
     the stem's output; here they run apart so that each can be looked at (the fused launch has its own test below)."""
     import torch.nn.functional as F
     from oracle import v5_ref as R
+    from yolo_amd import engine
     from yolo_amd.init import seeded_images, seeded_state_dict
-    monkeypatch.setenv("YAMD_NO_STEM_FUSION", "1")
+    monkeypatch.setitem(engine.FUSE, "stem_conv2", False)
     p, m = _model(128, 21, gpu_device)
     sd = seeded_state_dict(m, seed=21, mode="spread")
     imgs_np = seeded_images(2, 128, seed=21)
@@ -208,7 +209,8 @@ def test_v5s_fused_stem_and_next_conv(gpu_device, monkeypatch, size):
     with pytest.raises(Exception, match="not materialised"):
         prog.read_view(prog.taps["stem"], 3, gpu_device)
     fused = prog.read_view(prog.taps["dark2.0"], 3, gpu_device).cpu()
-    monkeypatch.setenv("YAMD_NO_STEM_FUSION", "1")
+    from yolo_amd import engine
+    monkeypatch.setitem(engine.FUSE, "stem_conv2", False)
     p2, m2 = _model(size, 33, gpu_device)
     m2.raw_heads(imgs.to(gpu_device))
     prog2 = m2.program()

@@ -29,6 +29,11 @@ class View(NamedTuple):
         return View(self.buf, self.coff + coff, c, self.h, self.w)
 
 
+# Which fused forms Program.conv may substitute while a model is recorded (all on; tests and layer-by-layer inspection
+# switch one off before building a model).  None of them changes a result beyond the bf16 rounding both forms share.
+FUSE = {"stem": True,          # first conv straight from the fp32 image (yamd_stem_conv)
+        "stem_conv2": True}    # stride-2 stem + the 3x3 stride-2 conv after it as one launch (yamd_stem_conv2)
+
 _PACK_GENERATION = [0]      # bumped whenever a layer's packed weights or descriptor change: compiled C plans are stale then
 
 
@@ -218,7 +223,7 @@ class Program:
         wo = (x.w + 2 * pad - k) // stride + 1
         if (x.buf in ("focus", "image16") and self.ops and self.ops[-1][0] in ("focus", "nhwc16") and self.ops[-1][1].buf == x.buf
                 and k == 3 and cout <= 64 and cout % 8 == 0 and residual is None and out2 is None and not out_f32
-                and (x.buf == "image16" or stride == 1) and not os.environ.get("YAMD_NO_STEM")):
+                and (x.buf == "image16" or stride == 1) and FUSE["stem"]):
             # the network's first conv reads the image itself: no packed copy of the image is written
             self.ops.pop()
             del self.buffers[x.buf]
@@ -232,7 +237,7 @@ class Program:
             return out
         if (self.ops and self.ops[-1][0] == "stem" and self.ops[-1][2] == x and k == 3 and stride == 2 and residual is None
                 and out2 is None and not out_f32 and StemConv2Layer.supported(self.ops[-1][1], cout)
-                and self.img_h % 2 == 0 and self.img_w % 2 == 0 and not os.environ.get("YAMD_NO_STEM_FUSION")):
+                and self.img_h % 2 == 0 and self.img_w % 2 == 0 and FUSE["stem_conv2"]):
             # the stem's only reader follows it directly: both run as one launch and the stem's output, the largest
             # activation of the network, is never written (a later reader of that buffer would find it unwritten, so the
             # buffer is dropped: recording such a reader fails in resolve())
@@ -455,7 +460,7 @@ class Program:
         buf, coff = self.resolve(v)
         if buf in self.fused_away:
             raise _lib.YamdError(f"activation '{buf}' is not materialised: its layer runs fused with the next one "
-                                 "(set YAMD_NO_STEM_FUSION=1 before building the model to inspect it)")
+                                 "(set yolo_amd.engine.FUSE['stem_conv2'] = False before building the model to inspect it)")
         return bufs[buf][..., coff:coff + v.c].permute(0, 3, 1, 2).float().contiguous()
 
     def n_conv_launches(self) -> int:
