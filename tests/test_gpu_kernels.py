@@ -351,6 +351,32 @@ def test_upsample_copy_maxpool(gpu_device):
         assert torch.equal(got[..., (i + 1) * c:(i + 2) * c], want), f"pool {k}"
 
 
+@pytest.mark.parametrize("H,W,c,kernel", [(20, 20, 256, 5), (13, 17, 64, 5), (40, 40, 128, 5), (64, 64, 8, 5), (19, 19, 24, 3),
+                                            (20, 20, 96, 3), (12, 40, 32, 5)])
+def test_maxpool_cascade_channel_groups(gpu_device, H, W, c, kernel):
+    """The pool cascade for plane sizes and channel counts that take 8, 4, 2 and 1 pieces of 8 channels per workgroup:
+    x in slice 1 of a 5-slice buffer, the three pools into slices 2..4, slice 0 untouched; exact against torch."""
+    from yolo_amd import lib as L
+    g = torch.Generator().manual_seed(H * 31 + c)
+    Bn = 2
+    cat = torch.zeros((Bn, H, W, 5 * c), dtype=torch.bfloat16)
+    cat[..., :c] = 7.0
+    src = torch.randn((Bn, H, W, c), generator=g).to(torch.bfloat16)
+    cat[..., c:2 * c] = src
+    cd = cat.to(gpu_device)
+    p = cd.data_ptr()
+    fn = L.LIB.yamd_maxpool5_cascade if kernel == 5 else L.LIB.yamd_maxpool3_cascade
+    L.check(fn(p + c * 2, 5 * c, p + 2 * c * 2, p + 3 * c * 2, p + 4 * c * 2, 5 * c, Bn, H, W, c, L.current_stream()))
+    torch.cuda.synchronize()
+    got = cd.cpu()
+    assert torch.all(got[..., :c] == 7.0) and torch.equal(got[..., c:2 * c], src)
+    s = src.float().permute(0, 3, 1, 2)
+    for i in range(3):
+        k = kernel + i * (kernel - 1)
+        want = F.max_pool2d(s, k, 1, k // 2).permute(0, 2, 3, 1).to(torch.bfloat16)
+        assert torch.equal(got[..., (i + 2) * c:(i + 3) * c], want), f"pool {k}"
+
+
 def test_maxpool2_and_conv_transpose(gpu_device):
     """MaxPool2d(2,2) exact; ConvTranspose2d(2,2)+bias = 1x1 conv to 4c channels + depth-to-space, through the
     engine ops, against torch fp32 on bf16-rounded operands (rel L2 <= 1e-2: one bf16 rounding of the output)."""

@@ -181,12 +181,16 @@ __global__ void copy_channels_kernel(const __bf16 *__restrict__ x, int x_cs, __b
     }
 }
 
-__device__ __forceinline__ bf16x8 max8(bf16x8 a, bf16x8 b)
+// Order-preserving 16-bit integer keys of bf16 values, two per 32-bit word: flipping the magnitude bits of the negative
+// values makes signed 16-bit integer order equal to numeric order (-0 sorts just below +0), and the map is its own
+// inverse.  A max over such keys is one packed integer instruction per two values, where comparing as floats costs a
+// conversion pair, a compare and a select per value.
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4v bf16_keys(u32x4v w) { return w ^ (((w >> 15) & 0x00010001u) * 0x7FFFu); }
+__device__ __forceinline__ u32x4v key_max8(u32x4v a, u32x4v b)
 {
-    bf16x8 r;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = ((float)a[i] > (float)b[i]) ? a[i] : b[i];
-    return r;
+    return __builtin_bit_cast(u32x4v, __builtin_elementwise_max(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b)));
 }
 
 __global__ void maxpool2_kernel(const __bf16 *__restrict__ x, int x_cs, __bf16 *__restrict__ y, int y_cs, int B, int H,
@@ -202,47 +206,55 @@ __global__ void maxpool2_kernel(const __bf16 *__restrict__ x, int x_cs, __bf16 *
         const int oy = (int)((pix / Wo) % Ho);
         const long long b = pix / ((long long)Wo * Ho);
         const __bf16 *s = x + ((b * H + 2 * oy) * W + 2 * ox) * x_cs + c8 * 8;
-        const bf16x8 a = *(const bf16x8 *)s, c = *(const bf16x8 *)(s + x_cs);
-        const bf16x8 d = *(const bf16x8 *)(s + (long long)W * x_cs), e = *(const bf16x8 *)(s + (long long)(W + 1) * x_cs);
-        *(bf16x8 *)(y + pix * y_cs + c8 * 8) = max8(max8(a, c), max8(d, e));
+        const u32x4v a = bf16_keys(*(const u32x4v *)s), c = bf16_keys(*(const u32x4v *)(s + x_cs));
+        const u32x4v d = bf16_keys(*(const u32x4v *)(s + (long long)W * x_cs)), e = bf16_keys(*(const u32x4v *)(s + (long long)(W + 1) * x_cs));
+        *(u32x4v *)(y + pix * y_cs + c8 * 8) = bf16_keys(key_max8(key_max8(a, c), key_max8(d, e)));
     }
 }
 
-// One workgroup per (image, 8-channel piece): the whole h*w plane of 16-byte pixels sits in LDS;
-// a (2R+1)x(2R+1) max is a row pass followed by a column pass, applied three times (R = 2: 5x5, R = 1: 3x3).
+// One workgroup per (image, group of G 8-channel pieces): the whole h*w plane of the group (16*G bytes per pixel) sits in
+// LDS; a (2R+1)x(2R+1) max is a row pass followed by a column pass, applied three times (R = 2: 5x5, R = 1: 3x3).
+// Consecutive lanes take consecutive 16-byte pieces of a pixel, so with G = 8 every global access moves whole 128-byte
+// lines (one piece per workgroup would fetch every line once per piece, from eight different L2s).
 template <int R>
 __global__ void maxpool_cascade_kernel(const __bf16 *__restrict__ x, int x_cs, __bf16 *__restrict__ y1,
-                                        __bf16 *__restrict__ y2, __bf16 *__restrict__ y3, int y_cs, int H, int W, int C8)
+                                        __bf16 *__restrict__ y2, __bf16 *__restrict__ y3, int y_cs, int H, int W, int groups,
+                                        int G)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16x8 *cur = (bf16x8 *)smem;
-    bf16x8 *tmp = cur + H * W;
-    const int c8 = blockIdx.x % C8;
-    const long long b = blockIdx.x / C8;
-    const int n = H * W;
-    for (int i = threadIdx.x; i < n; i += blockDim.x)
-        cur[i] = *(const bf16x8 *)(x + (b * n + i) * x_cs + c8 * 8);
+    u32x4v *cur = (u32x4v *)smem;                          // the plane as integer keys (bf16_keys)
+    const int n = H * W, total = n * G;
+    u32x4v *tmp = cur + total;
+    const int c0 = (blockIdx.x % groups) * G * 8;          // first channel of the group
+    const long long b = blockIdx.x / groups;
+    const int gshift = G == 8 ? 3 : (G == 4 ? 2 : (G == 2 ? 1 : 0));
+    for (int i = threadIdx.x; i < total; i += blockDim.x)
+        cur[i] = bf16_keys(*(const u32x4v *)(x + (b * n + (i >> gshift)) * x_cs + c0 + (i & (G - 1)) * 8));
     __syncthreads();
     __bf16 *outs[3] = {y1, y2, y3};
     for (int pass = 0; pass < 3; ++pass) {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const int r = i / W, c = i % W;
-            bf16x8 m = cur[i];
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const int pix = i >> gshift, g = i & (G - 1);
+            const int r = pix / W, c = pix - r * W;
+            u32x4v m = cur[i];
+#pragma unroll
             for (int d = -R; d <= R; ++d) {
                 const int cc = c + d;
-                if (d != 0 && cc >= 0 && cc < W) m = max8(m, cur[r * W + cc]);
+                if (d != 0 && cc >= 0 && cc < W) m = key_max8(m, cur[((r * W + cc) << gshift) + g]);
             }
             tmp[i] = m;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const int r = i / W, c = i % W;
-            bf16x8 m = tmp[i];
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            const int pix = i >> gshift, g = i & (G - 1);
+            const int r = pix / W, c = pix - r * W;
+            u32x4v m = tmp[i];
+#pragma unroll
             for (int d = -R; d <= R; ++d) {
                 const int rr = r + d;
-                if (d != 0 && rr >= 0 && rr < H) m = max8(m, tmp[rr * W + c]);
+                if (d != 0 && rr >= 0 && rr < H) m = key_max8(m, tmp[((rr * W + c) << gshift) + g]);
             }
-            *(bf16x8 *)(outs[pass] + (b * n + i) * y_cs + c8 * 8) = m;
+            *(u32x4v *)(outs[pass] + (b * n + pix) * y_cs + c0 + g * 8) = bf16_keys(m);
             // the column pass reads tmp only, so cur can be overwritten for the next pass
             cur[i] = m;
         }
@@ -346,15 +358,18 @@ int maxpool_cascade(int radius, const void *x, int x_cstride, void *y1, void *y2
     YAMD_REQUIRE(x_cstride % 8 == 0 && y_cstride % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y1 % 16) == 0 &&
                      ((uintptr_t)y2 % 16) == 0 && ((uintptr_t)y3 % 16) == 0,
                  "maxpool needs 16-byte aligned pixels");
-    const size_t lds = (size_t)h * w * 16 * 2;
+    // pieces per workgroup: as many as fit 128 KB of LDS (two planes), at most 8 (= whole 128-byte lines), dividing c / 8
+    int G = 8;
+    while (G > 1 && ((size_t)h * w * 32 * G > 128 * 1024 || (c / 8) % G != 0)) G >>= 1;
+    const size_t lds = (size_t)h * w * 16 * 2 * G;
     auto kern = radius == 2 ? maxpool_cascade_kernel<2> : maxpool_cascade_kernel<1>;
     {
         const int rc = radius == 2 ? KernelAttr<&maxpool_cascade_kernel<2>, 128 * 1024>::ensure()
                                    : KernelAttr<&maxpool_cascade_kernel<1>, 128 * 1024>::ensure();
         if (rc != YAMD_OK) return rc;
     }
-    hipLaunchKernelGGL(kern, dim3(batch * (c / 8)), dim3(256), lds, (hipStream_t)stream, (const __bf16 *)x, x_cstride,
-                       (__bf16 *)y1, (__bf16 *)y2, (__bf16 *)y3, y_cstride, h, w, c / 8);
+    hipLaunchKernelGGL(kern, dim3(batch * (c / 8 / G)), dim3(G >= 4 ? 512 : 256), lds, (hipStream_t)stream, (const __bf16 *)x,
+                       x_cstride, (__bf16 *)y1, (__bf16 *)y2, (__bf16 *)y3, y_cstride, h, w, c / 8 / G, G);
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
 }
