@@ -111,6 +111,7 @@ def dist_setup(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if not args.dry:
+            local %= max(1, torch.cuda.device_count())      # more ranks than GPUs (a rehearsal on one GPU): ranks share devices
             torch.cuda.set_device(local)
         dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
     return world, rank, local
