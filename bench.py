@@ -216,6 +216,7 @@ def stage_profile(model, images, reps=3):
     return dict(table=table, pred=pred,
                 conv_ms=sum(r["ms"] for r in table if r["kind"] == "conv"),
                 conv_flops=sum(r["flops"] for r in table if r["kind"] == "conv"),
+                conv_bytes=sum(r["bytes"] for r in table if r["kind"] == "conv"),
                 n_conv=sum(1 for r in table if r["kind"] == "conv"), decode_ms=dec_ms, decode_bytes=dec_bytes,
                 nms_ms=nms_ms, other_ms=sum(r["ms"] for r in table if r["kind"] != "conv"))
 
@@ -524,6 +525,10 @@ def main():
                          "conv_ms_in_pipeline": round(conv_ms_pipe, 3),
                          "conv_ms_isolated": round(prof["conv_ms"], 3),
                          "achieved_isolated": round(conv_tflops_iso, 2)},
+            # the same launches against the other roof: every conv's input, output, residual and weights counted once
+            "conv_hbm": {"algorithmic_GB_per_step": round(prof["conv_bytes"] / 1e9, 2),
+                         "achieved_GBs": round(prof["conv_bytes"] / (conv_ms_pipe * 1e-3) / 1e9, 1), "peak_GBs": PEAK_HBM_GBS,
+                         "frac": round(prof["conv_bytes"] / (conv_ms_pipe * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)},
             "stages_ms": {"conv": round(prof["conv_ms"], 3), "layout_pool_upsample": round(prof["other_ms"], 3),
                           "decode": round(prof["decode_ms"], 3), "nms": round(prof["nms_ms"], 3)},
             "decode_hbm": {"achieved_GBs": round(prof["decode_bytes"] / (prof["decode_ms"] * 1e-3) / 1e9, 1),
@@ -553,6 +558,7 @@ def main():
             out["roofline"]["frac_at_sustained_clock"] = round(conv_tflops / (PEAK_BF16_TFLOPS * clk_conv["GHz"] / 2.4), 4)
             out["roofline"]["frac_of_measured_mfma_loop"] = round(conv_tflops / peaks["mfma_bf16_TFLOPs"], 4)
             out["decode_hbm"]["frac_of_measured_copy"] = round(out["decode_hbm"]["achieved_GBs"] / peaks["hbm_copy_GBs"], 4)
+            out["conv_hbm"]["frac_of_measured_copy"] = round(out["conv_hbm"]["achieved_GBs"] / peaks["hbm_copy_GBs"], 4)
             if world == 1 and not args.two_stream:
                 out["two_stream"] = two_stream_rate(model, images, sink, dev, args.steps)
             if args.model == "v5s" and world == 1:      # (loads other weights: keep it behind everything that needs the headline's)

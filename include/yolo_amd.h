@@ -100,6 +100,18 @@ int yamd_conv2d_bias_act_split(const yamd_conv_desc *d, const void *x, int x_cst
                                const float *bias_packed, void *y, int y_cstride, void *y2, int y2_cstride,
                                int split_cout, int batch, int h, int w, void *stream);
 
+/* A 1x1 conv whose input is torch.cat((a, b), 1) with either part optionally behind nn.Upsample(scale_factor=2,
+ * mode="nearest"), without building the concatenation or the upsampled tensor:
+ *     p5_up_sample = self.up_sample(p5); p4 = torch.cat([p5_up_sample, feat2], 1); p4 = self.conv3_for_up_sample1(p4)
+ * (yolov5/YoloV5Body.py:232-235 and :237-240, yolov8/YoloV8Body.py:292-297; the first conv(s) of the C3 / C2f block read
+ * the cat).  xa holds the first ca input channels, xb the remaining d->cin - ca; xa_half / xb_half = 1: that tensor is
+ * (batch, h/2, w/2, *) and pixel (y, x) reads its pixel (y/2, x/2).  ca and d->cin - ca must be multiples of d->ck.
+ * y2 = NULL: all output channels to y; otherwise split as in yamd_conv2d_bias_act_split.  No residual. */
+int yamd_conv2d_bias_act_cat2(const yamd_conv_desc *d, const void *xa, int xa_cstride, int ca, int xa_half,
+                              const void *xb, int xb_cstride, int xb_half, const void *w_packed,
+                              const float *bias_packed, void *y, int y_cstride, void *y2, int y2_cstride,
+                              int split_cout, int batch, int h, int w, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Layout / resampling helpers of the conv graph.
  * ---------------------------------------------------------------------------------------- */
@@ -327,11 +339,13 @@ enum {
     YAMD_OP_MAXPOOL3_CASCADE = 9, /* yamd_maxpool3_cascade: i = {x_cstride, y_cstride, h, w, c} */
     YAMD_OP_MAXPOOL2 = 10,        /* yamd_maxpool2: i = {x_cstride, y_cstride, h, w, c} */
     YAMD_OP_DEPTH_TO_SPACE2 = 11, /* yamd_depth_to_space2: i = {x_cstride, y_cstride, h, w, c (of the output)} */
-    YAMD_OP_COPY_CHANNELS = 12    /* yamd_copy_channels over batch*h*w pixels: i = {x_cstride, y_cstride, h, w, c} */
+    YAMD_OP_COPY_CHANNELS = 12,   /* yamd_copy_channels over batch*h*w pixels: i = {x_cstride, y_cstride, h, w, c} */
+    YAMD_OP_CONV_CAT2 = 13        /* yamd_conv2d_bias_act_cat2: desc; p[0] = xa, p[3] = xb, p[5] = y2 or NULL;
+                                   * i = {xa_cstride, xb_cstride, y_cstride, h, w, y2_cstride, split_cout, ca, xa_half | xb_half << 1} */
 };
 typedef struct yamd_plan_op {
     int32_t kind;
-    int32_t i[8];
+    int32_t i[9];
     void *p[7];
     yamd_conv_desc desc;          /* YAMD_OP_CONV / YAMD_OP_CONV_SPLIT only */
 } yamd_plan_op;

@@ -31,6 +31,7 @@ extern "C" int conv_trace_run(const void *x, int x_cs, const void *w, const floa
     const int th_max = (TR_NW * 32 * MREP) / TW;
     p.tiles_x = ceil_div(p.Wout, TW); p.tiles_y = ceil_div(p.Hout, th_max); p.TH = ceil_div(p.Hout, p.tiles_y);
     p.n_tiles = ((cout + NREP * 32 - 1) / (NREP * 32)); p.nchunks = cin / CK;
+    p.x2 = nullptr; p.x2_cs = 0; p.nsplit = p.nchunks; p.half1 = p.half2 = 0; p.oH = h; p.oW = wd;
 #ifdef YAMD_CONV_TRACE
     p.trace = trace;
 #endif

@@ -13,18 +13,19 @@ m.load_state_dict(seeded_state_dict(m, seed=0, mode="torch_default"))
 dev = torch.device("cuda:0")
 x = torch.rand(B, 3, p.img_size, p.img_size, device=dev)
 prog = m.program()
-for _ in range(reps):
+prog.run(x)
+for _ in range(reps - 1):
     prog.run(x)
 torch.cuda.synchronize()
 ops = []
 for op in prog.ops:
     fl, by = prog.op_cost(op, B)
     kind = op[0]
-    name_ = getattr(op[1], "name", kind) if kind in ("conv", "stem", "stem2") else kind
+    name_ = getattr(op[1], "name", kind) if kind in ("conv", "conv_cat2", "stem", "stem2") else kind
     desc = ""
-    if kind == "conv":
+    if kind in ("conv", "conv_cat2"):
         d = op[1].desc
-        o = op[3]
+        o = op[3] if kind == "conv" else op[6]
         desc = f"k{d.ksize}s{d.stride} {d.cin}>{d.cout} @{o.h}x{o.w} tiling={op[1].tiling}"
     launches = 1
     ops.append(dict(kind=kind, name=name_, desc=desc, flops=fl, bytes=by))

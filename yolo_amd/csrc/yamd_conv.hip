@@ -155,9 +155,15 @@ extern "C" int yamd_conv_pack_weights(const yamd_conv_desc *d, const float *w, i
 }
 
 namespace {
+// a 1x1 conv over torch.cat((a, b), 1): the first `ca` input channels come from x, the others from xb; *_half: stored at
+// half the resolution (read through nearest-neighbour upsampling)
+struct CatInput {
+    const void *xb = nullptr;
+    int xb_cstride = 0, ca = 0, a_half = 0, b_half = 0;
+};
 int conv_impl(const yamd_conv_desc *d, const void *x, int x_cstride, const void *w_packed, const float *bias_packed,
               const void *residual, int res_cstride, void *y, int y_cstride, void *y2, int y2_cstride, int split, int batch, int h,
-              int w, void *stream);
+              int w, void *stream, const CatInput &cat = CatInput());
 }
 
 extern "C" int yamd_conv2d_bias_act(const yamd_conv_desc *d, const void *x, int x_cstride, const void *w_packed,
@@ -181,16 +187,52 @@ extern "C" int yamd_conv2d_bias_act_split(const yamd_conv_desc *d, const void *x
     return conv_impl(d, x, x_cstride, w_packed, bias_packed, nullptr, 0, y, y_cstride, y2, y2_cstride, split_cout, batch, h, w, stream);
 }
 
+extern "C" int yamd_conv2d_bias_act_cat2(const yamd_conv_desc *d, const void *xa, int xa_cstride, int ca, int xa_half,
+                                         const void *xb, int xb_cstride, int xb_half, const void *w_packed,
+                                         const float *bias_packed, void *y, int y_cstride, void *y2, int y2_cstride,
+                                         int split_cout, int batch, int h, int w, void *stream)
+{
+    YAMD_REQUIRE(d && xb, "null argument");
+    YAMD_REQUIRE(d->ksize == 1 && d->stride == 1, "a concatenated input is built for 1x1 convs");
+    YAMD_REQUIRE(ca > 0 && ca < d->cin && ca % d->ck == 0 && (d->cin - ca) % d->ck == 0,
+                 "the first source's %d of %d channels must be a multiple of the staged chunk (%d)", ca, d->cin, d->ck);
+    YAMD_REQUIRE((xa_half == 0 || xa_half == 1) && (xb_half == 0 || xb_half == 1), "half flags are 0 or 1");
+    YAMD_REQUIRE(!(xa_half || xb_half) || (h % 2 == 0 && w % 2 == 0), "a half-resolution source needs even h, w (%dx%d)", h, w);
+    YAMD_REQUIRE(xb_cstride >= d->cin - ca && xb_cstride % 8 == 0 && ((uintptr_t)xb % 16) == 0,
+                 "second input needs 16-byte aligned pixels (cstride=%d)", xb_cstride);
+    // 32-bit element offsets: a full-resolution source is addressed inside one image (the launcher re-cuts the batch so
+    // that this holds), a half-resolution source from its first element
+    YAMD_REQUIRE((long long)h * w * xb_cstride < (1ll << 31), "one input image must stay below 2^31 elements");
+    YAMD_REQUIRE(!xa_half || (long long)batch * (h / 2) * (w / 2) * xa_cstride < (1ll << 31), "half-resolution source above 2^31 elements");
+    YAMD_REQUIRE(!xb_half || (long long)batch * (h / 2) * (w / 2) * xb_cstride < (1ll << 31), "half-resolution source above 2^31 elements");
+    YAMD_REQUIRE((long long)batch * h * w < (1ll << 31), "more than 2^31 pixels");
+    if (y2) {
+        YAMD_REQUIRE(!d->out_f32, "split output is built for bf16 outputs");
+        YAMD_REQUIRE(split_cout > 0 && split_cout < d->cout && split_cout % 8 == 0, "split at cout %d of %d", split_cout, d->cout);
+        YAMD_REQUIRE(y_cstride >= split_cout && y2_cstride >= d->cout - split_cout && y2_cstride % 8 == 0 && ((uintptr_t)y2 % 16) == 0,
+                     "split outputs need 16-byte aligned pixels (cstrides %d, %d)", y_cstride, y2_cstride);
+    }
+    CatInput cat;
+    cat.xb = xb;
+    cat.xb_cstride = xb_cstride;
+    cat.ca = ca;
+    cat.a_half = xa_half;
+    cat.b_half = xb_half;
+    return conv_impl(d, xa, xa_cstride, w_packed, bias_packed, nullptr, 0, y, y_cstride, y2, y2 ? y2_cstride : 0,
+                     y2 ? split_cout : d->cout, batch, h, w, stream, cat);
+}
+
 namespace {
 int conv_impl(const yamd_conv_desc *d, const void *x, int x_cstride, const void *w_packed, const float *bias_packed,
               const void *residual, int res_cstride, void *y, int y_cstride, void *y2, int y2_cstride, int split, int batch, int h,
-              int w, void *stream)
+              int w, void *stream, const CatInput &cat)
 {
     YAMD_REQUIRE(d && x && w_packed && bias_packed && y, "null argument");
     YAMD_REQUIRE(batch > 0 && h > 0 && w > 0, "bad shape %dx%dx%d", batch, h, w);
     YAMD_REQUIRE((long long)h * w * x_cstride < (1ll << 31), "one input image must stay below 2^31 elements");
-    YAMD_REQUIRE(x_cstride >= d->cin && x_cstride % 8 == 0 && ((uintptr_t)x % 16) == 0,
+    YAMD_REQUIRE(x_cstride >= (cat.xb ? cat.ca : d->cin) && x_cstride % 8 == 0 && ((uintptr_t)x % 16) == 0,
                  "input needs 16-byte aligned pixels (cstride=%d)", x_cstride);
+    const int orig_h = h, orig_w = w;
     YAMD_REQUIRE(((uintptr_t)w_packed % 16) == 0, "packed weights must be 16-byte aligned");
     if (!d->out_f32) {
         YAMD_REQUIRE(y_cstride >= (split < d->cout ? split : d->cout) && y_cstride % 8 == 0 && ((uintptr_t)y % 16) == 0,
@@ -211,7 +253,8 @@ int conv_impl(const yamd_conv_desc *d, const void *x, int x_cstride, const void 
         const int tw = (w % 20 == 0 && w % 16 != 0) ? 20 : 16;
         if (px % tw == 0) {
             // split into the fewest images that stay below 2^31 elements each (32-bit offsets inside an image)
-            const long long widest = x_cstride > y_cstride ? x_cstride : y_cstride;
+            long long widest = x_cstride > y_cstride ? x_cstride : y_cstride;
+            if (cat.xb_cstride > widest) widest = cat.xb_cstride;
             long long parts = 1;
             while (parts <= batch && ((px / parts) * widest >= (1ll << 31) || px % (parts * tw) != 0 || batch % parts != 0)) ++parts;
             if (parts <= batch) {
@@ -264,6 +307,13 @@ int conv_impl(const yamd_conv_desc *d, const void *x, int x_cstride, const void 
     }
     p.n_tiles = d->cout_pad / (d->nrep * 32);
     p.nchunks = d->cin / d->ck;
+    p.x2 = (const __bf16 *)cat.xb;
+    p.x2_cs = cat.xb_cstride;
+    p.nsplit = cat.xb ? cat.ca / d->ck : p.nchunks;
+    p.half1 = cat.a_half;
+    p.half2 = cat.b_half;
+    p.oH = orig_h;
+    p.oW = orig_w;
     hipStream_t st = (hipStream_t)stream;
 
     const int stages = d->stages == 2 ? 2 : 1;

@@ -52,6 +52,13 @@ struct ConvParams {
     // fill them.  0 = off.
     int vin, vout, vbatch;
     float res_scale;             // weight of the residual in the sum
+    // 1x1 convs over a channel concatenation of two tensors (torch.cat((a, b), 1) feeding a conv) without building the
+    // concatenation: chunks [0, nsplit) come from x, chunks [nsplit, nchunks) from x2.  half1 / half2: that source is
+    // stored at half the resolution and read through nearest-neighbour upsampling (nn.Upsample(scale_factor=2) feeding
+    // the cat), addressed from the pixel's position in the original oH x oW image.  Single source: x2 = nullptr,
+    // nsplit = nchunks, half1 = half2 = 0.
+    const __bf16 *x2;
+    int x2_cs, nsplit, half1, half2, oH, oW;
 #ifdef YAMD_CONV_TRACE
     unsigned long long *trace;   // 8 timestamps per workgroup (profiling builds only)
 #endif
@@ -219,6 +226,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
     // The per-piece global offset (inside this image), LDS offset and in-image flag do not depend on the
     // channel chunk, so they are computed once.
     int goff[AP], loff[AP];
+    int goff2[KS == 1 ? AP : 1];     // second source (1x1 convs over a concatenation)
     unsigned inb_mask = 0u;
     static_for<AP>([&](auto uc) __attribute__((always_inline)) {
         constexpr int u = decltype(uc)::value;
@@ -238,12 +246,37 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
         inb = inb && ih >= 0 && ih < p.H;
         const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1);
         goff[u] = ((img_row0 + ihc) * p.W + iwc) * p.x_cs + gc * 8;
+        if constexpr (KS == 1) {
+            goff2[u] = ((img_row0 + ihc) * p.W + iwc) * p.x2_cs + gc * 8;
+            if (p.half1 | p.half2) {      // uniform
+                // position of the pixel in the original images (the 1x1 launcher may have re-cut the batch into strips;
+                // the pixel order is the same), then the pixel of the half-resolution tensor under it
+                const int gp = (b * p.H + ihc) * p.W + iwc, hw = p.oH * p.oW;
+                const int ob = gp / hw, rem = gp - ob * hw;
+                const int oy = rem / p.oW, ox = rem - oy * p.oW;
+                const int hp = (ob * (p.oH >> 1) + (oy >> 1)) * (p.oW >> 1) + (ox >> 1);
+                if (p.half1) goff[u] = hp * p.x_cs + gc * 8;
+                if (p.half2) goff2[u] = hp * p.x2_cs + gc * 8;
+            }
+        }
         const int lc = (S == 2) ? ((hc & 1) * NPWH + (hc >> 1)) : hc;
         if constexpr (COMPACT) loff[u] = (hr * CROW + lc) * 32 + ((gc ^ Lds::swz(hr, lc)) << 4);
         else loff[u] = (hr * NPW + lc) * RS + gc * 16;
         inb_mask |= inb ? (1u << u) : 0u;
     });
-    const __bf16 *ximg = p.x + (size_t)b * p.H * p.W * p.x_cs;
+    // offsets into a half-resolution source count from the tensor's first element, the others from the image's
+    const __bf16 *ximg = (KS == 1 && p.half1) ? p.x : p.x + (size_t)b * p.H * p.W * p.x_cs;
+    const __bf16 *x2img = (KS == 1 && !p.half2 && p.x2) ? p.x2 + (size_t)b * p.H * p.W * p.x2_cs : p.x2;
+    // piece u of the activation chunk c
+    auto load_piece = [&](int c, int off1, int off2) __attribute__((always_inline)) -> u32x4 {
+        if constexpr (KS == 1) {
+            const bool second = c >= p.nsplit;      // uniform
+            const __bf16 *xc = second ? x2img + (c - p.nsplit) * CK : ximg + c * CK;
+            return *(const u32x4 *)(xc + (second ? off2 : off1));
+        } else {
+            return *(const u32x4 *)(ximg + c * CK + off1);
+        }
+    };
     const char *wtile = p.w + (size_t)nt0 * p.nchunks * WBYTES;
     auto issue_loads = [&](int ch) __attribute__((always_inline)) {
         const char *wsrc = wtile + (size_t)ch * WBYTES;
@@ -252,10 +285,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
             const int q = min(tid + u * NT, WBYTES / 16 - 1);
             rw[u] = *(const u32x4 *)(wsrc + q * 16);
         });
-        const __bf16 *xc = ximg + ch * CK;
         static_for<AP>([&](auto uc) __attribute__((always_inline)) {
             constexpr int u = decltype(uc)::value;
-            ra[u] = *(const u32x4 *)(xc + goff[u]);
+            ra[u] = load_piece(ch, goff[u], goff2[KS == 1 ? u : 0]);
         });
     };
     // one LDS image: weights, then the halo tile (multiple of 16).  With two images the epilogue of a cout tile runs
@@ -568,14 +600,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
         {
             const int l1 = min(1, last), c1 = l1 % p.nchunks;
             const char *wsrc = p.w + (size_t)l1 * WBYTES;
-            const __bf16 *xc = ximg + c1 * CK;
             static_for<WP>([&](auto uc) __attribute__((always_inline)) {
                 constexpr int u = decltype(uc)::value;
                 rw[u] = *(const u32x4 *)(wsrc + min(tid + u * NT, WBYTES / 16 - 1) * 16);
             });
             static_for<AP>([&](auto uc) __attribute__((always_inline)) {
                 constexpr int u = decltype(uc)::value;
-                ra[u] = *(const u32x4 *)(xc + goff[u]);
+                ra[u] = load_piece(c1, goff[u], goff2[KS == 1 ? u : 0]);
             });
         }
         int lnext = min(2, last), cnext = lnext % p.nchunks;      // the chunk the next loads fetch, and its index inside its cout tile
@@ -593,7 +624,6 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
                 char *nxtW = smem + (stage_bytes - cur);
                 char *nxtA = nxtW + WBYTES;
                 const char *wsrc = p.w + (size_t)lnext * WBYTES;
-                const __bf16 *xc = ximg + cnext * CK;
                 compute_chunk(cur, [&](auto sc) __attribute__((always_inline)) {
                     constexpr int slot = decltype(sc)::value;
                     constexpr int u0 = slot * NPIECE / NSLOT, u1 = (slot + 1) * NPIECE / NSLOT;
@@ -606,7 +636,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
                         } else {
                             constexpr int v = u - WP;
                             *(u32x4 *)(nxtA + loff[v]) = ((inb_mask >> v) & 1u) ? ra[v] : u32x4{0u, 0u, 0u, 0u};
-                            ra[v] = *(const u32x4 *)(xc + goff[v]);
+                            ra[v] = load_piece(cnext, goff[v], goff2[KS == 1 ? v : 0]);
                         }
                     });
                 });

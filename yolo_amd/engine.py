@@ -32,7 +32,8 @@ class View(NamedTuple):
 # Which fused forms Program.conv may substitute while a model is recorded (all on; tests and layer-by-layer inspection
 # switch one off before building a model).  None of them changes a result beyond the bf16 rounding both forms share.
 FUSE = {"stem": True,          # first conv straight from the fp32 image (yamd_stem_conv)
-        "stem_conv2": True}    # stride-2 stem + the 3x3 stride-2 conv after it as one launch (yamd_stem_conv2)
+        "stem_conv2": True,    # stride-2 stem + the 3x3 stride-2 conv after it as one launch (yamd_stem_conv2)
+        "upsample_cat": True}  # 1x1 convs read torch.cat((up(a), b), 1) from a and b themselves (yamd_conv2d_bias_act_cat2)
 
 _PACK_GENERATION = [0]      # bumped whenever a layer's packed weights or descriptor change: compiled C plans are stale then
 
@@ -190,6 +191,8 @@ class Program:
         self._n = 0
         self.span_sink: Optional[list] = None    # when set, every run() appends its conv spans here (see run)
         self.fused_away: set = set()             # buffers whose producer was merged into its consumer: never written
+        self.unwritten: List[Tuple[str, int, int]] = []   # (buffer, first channel, end): slices no op writes any more
+        self._finalized = False
 
     # ---- recording -------------------------------------------------------------------------------
     def buffer(self, h: int, w: int, c: int, dtype=torch.bfloat16, name: Optional[str] = None) -> View:
@@ -461,16 +464,22 @@ class Program:
         if buf in self.fused_away:
             raise _lib.YamdError(f"activation '{buf}' is not materialised: its layer runs fused with the next one "
                                  "(set yolo_amd.engine.FUSE['stem_conv2'] = False before building the model to inspect it)")
+        if any(b == buf and c0 < coff + v.c and c1 > coff for b, c0, c1 in self.unwritten):
+            raise _lib.YamdError(f"activation '{buf}'[{coff}:{coff + v.c}] is not materialised: its readers take the upsampled "
+                                 "tensor from the low-resolution one (set yolo_amd.engine.FUSE['upsample_cat'] = False before "
+                                 "building the model to inspect it)")
         return bufs[buf][..., coff:coff + v.c].permute(0, 3, 1, 2).float().contiguous()
 
     def n_conv_launches(self) -> int:
-        return sum(1 for op in self.ops if op[0] in ("conv", "stem", "stem2"))
+        return sum(1 for op in self.ops if op[0] in ("conv", "conv_cat2", "stem", "stem2"))
 
     def conv_macs_per_image(self) -> int:
         total = 0
         for op in self.ops:
             if op[0] == "conv":
                 total += op[1].macs_per_pixel * op[3].h * op[3].w
+            elif op[0] == "conv_cat2":
+                total += op[1].macs_per_pixel * op[6].h * op[6].w
             elif op[0] == "stem":
                 total += op[1].macs_per_pixel * op[2].h * op[2].w
             elif op[0] == "stem2":      # the MACs of the two layers, not of the fused kernel (which recomputes tile overlaps)
@@ -496,6 +505,12 @@ class Program:
             if res is not None:
                 byts += px * out.c * 2
             return flops, float(byts)
+        if kind == "conv_cat2":
+            _, layer, xa, _ah, xb, _bh, out, out2 = op
+            px = batch * out.h * out.w
+            cout = out.c + (out2.c if out2 is not None else 0)
+            byts = batch * (xa.h * xa.w * xa.c + xb.h * xb.w * xb.c) * 2 + px * cout * (4 if layer.desc.out_f32 else 2) + layer.macs_per_pixel * 2
+            return 2.0 * layer.macs_per_pixel * px, float(byts)
         if kind == "stem":
             _, layer, out = op
             px = batch * out.h * out.w
@@ -523,7 +538,67 @@ class Program:
         return 0.0, 0.0
 
     # ---- execution -------------------------------------------------------------------------------
+    @staticmethod
+    def _inputs_of(op) -> List[View]:
+        kind = op[0]
+        if kind == "conv":
+            return [v for v in (op[2], op[4]) if v is not None]
+        if kind == "conv_cat2":
+            return [op[2], op[4]]
+        if kind in ("up2", "copy", "d2s", "mp2", "mp5"):
+            return [op[1]]
+        return []
+
+    def fuse_upsample_cat(self) -> int:
+        """Removes every 2x upsampling whose output is one end of a concatenation that only 1x1 convs read: those convs
+        then read the low-resolution tensor and the other part themselves (``conv_cat2`` ops), and neither the
+        upsampled tensor nor its slice of the concatenation is ever written.  Returns the number of upsamplings
+        removed.  Runs once, before the first buffers are allocated."""
+        def rng(v: View):
+            buf, coff = self.resolve(v)
+            return buf, coff, coff + v.c
+
+        removed = 0
+        for up in [op for op in self.ops if op[0] == "up2"]:
+            _, low, out = up
+            obuf, o0, o1 = rng(out)
+            if any(rng(v)[0] == obuf and rng(v)[1] < o1 and rng(v)[2] > o0 for v in self.outputs.values()):
+                continue
+            readers, ok = [], True
+            for j, op in enumerate(self.ops):
+                if op is up:
+                    continue
+                for v in self._inputs_of(op):
+                    b, c0, c1 = rng(v)
+                    if b != obuf or c0 >= o1 or c1 <= o0:
+                        continue
+                    layer = op[1] if op[0] == "conv" else None
+                    # a 1x1 conv without residual whose input is exactly [upsampled part | other part] or the reverse
+                    fits = (op[0] == "conv" and v is op[2] and op[4] is None and layer._args[0] == 1 and c0 <= o0 and o1 <= c1
+                            and (c0 == o0) != (c1 == o1) and (o1 - o0) % layer.desc.ck == 0
+                            and (c1 - c0 - (o1 - o0)) % layer.desc.ck == 0)
+                    if not fits:
+                        ok = False
+                    else:
+                        readers.append((j, c0, c1))
+            if not ok or not readers:
+                continue
+            for j, c0, c1 in readers:
+                _, layer, x, y, _res, y2 = self.ops[j]
+                first = c0 == o0                     # the upsampled part comes first in the concatenation
+                other = View(x.buf, x.coff + ((o1 - o0) if first else 0), (c1 - c0) - (o1 - o0), x.h, x.w)
+                xa, xb = (low, other) if first else (other, low)
+                self.ops[j] = ("conv_cat2", layer, xa, int(first), xb, int(not first), y, y2)
+            self.ops.remove(up)
+            self.unwritten.append((obuf, o0, o1))
+            removed += 1
+        return removed
+
     def _buffers_for(self, batch: int, device) -> Dict[str, torch.Tensor]:
+        if not self._finalized:
+            self._finalized = True
+            if FUSE["upsample_cat"]:
+                self.fuse_upsample_cat()
         key = (batch, str(device))
         if key not in self._alloc:
             self._alloc.clear()   # one live batch size at a time: the arena is large
@@ -575,6 +650,16 @@ class Program:
                     rp, rcs = P(bufs, res) if res is not None else (None, 0)
                     fill(_lib.OP_CONV, (xcs, rcs, ycs, x.h, x.w),
                          {0: xp, 1: layer.w_dev.data_ptr(), 2: layer.b_dev.data_ptr(), 3: rp, 4: yp})
+                names.append(f"conv[{layer.name}]")
+            elif kind == "conv_cat2":
+                _, layer, xa, a_half, xb, b_half, out, out2 = op
+                xap, xacs = P(bufs, xa)
+                xbp, xbcs = P(bufs, xb)
+                yp, ycs = P(bufs, out)
+                y2p, y2cs = P(bufs, out2) if out2 is not None else (None, 0)
+                o.desc = layer.desc
+                fill(_lib.OP_CONV_CAT2, (xacs, xbcs, ycs, out.h, out.w, y2cs, out.c if out2 is not None else 0, xa.c, a_half | (b_half << 1)),
+                     {0: xap, 1: layer.w_dev.data_ptr(), 2: layer.b_dev.data_ptr(), 3: xbp, 4: yp, 5: y2p})
                 names.append(f"conv[{layer.name}]")
             elif kind == "stem":
                 _, layer, out = op
@@ -647,7 +732,7 @@ class Program:
         for op in self.ops:
             kind = op[0]
             if conv_spans is not None:
-                is_conv = kind in ("conv", "stem", "stem2")
+                is_conv = kind in ("conv", "conv_cat2", "stem", "stem2")
                 if is_conv and span_open is None:
                     span_open = torch.cuda.Event(enable_timing=True)
                     span_open.record()
@@ -673,6 +758,15 @@ class Program:
                     _lib.check(LIB.yamd_conv2d_bias_act(ctypes.byref(layer.desc), xp, xcs, layer.w_dev.data_ptr(),
                                                         layer.b_dev.data_ptr(), rp, rcs, yp, ycs, B, x.h, x.w, st),
                                f"conv[{layer.name}]")
+            elif kind == "conv_cat2":
+                _, layer, xa, a_half, xb, b_half, out, out2 = op
+                xap, xacs = P(bufs, xa)
+                xbp, xbcs = P(bufs, xb)
+                yp, ycs = P(bufs, out)
+                y2p, y2cs = P(bufs, out2) if out2 is not None else (None, 0)
+                _lib.check(LIB.yamd_conv2d_bias_act_cat2(ctypes.byref(layer.desc), xap, xacs, xa.c, a_half, xbp, xbcs, b_half,
+                                                         layer.w_dev.data_ptr(), layer.b_dev.data_ptr(), yp, ycs, y2p, y2cs,
+                                                         out.c if out2 is not None else 0, B, out.h, out.w, st), f"conv[{layer.name}]")
             elif kind == "stem":
                 _, layer, out = op
                 yp, ycs = P(bufs, out)
@@ -724,7 +818,7 @@ class Program:
             if timings is not None:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
-                if kind in ("stem", "stem2"):          # reported with the convs: the first conv layer(s)
+                if kind in ("stem", "stem2", "conv_cat2"):          # reported with the convs
                     timings.append(("conv", op[1].name, ev0, ev1) + self.op_cost(op, B))
                 else:
                     timings.append((kind, op[1].name if kind == "conv" else kind, ev0, ev1) + self.op_cost(op, B))

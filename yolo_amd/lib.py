@@ -17,7 +17,7 @@ DECODE_V5, DECODE_V3, DECODE_POSE, DECODE_FACE = 0, 1, 2, 3
 
 # every symbol include/yolo_amd.h declares
 EXPORTS = [
-    "yamd_last_error", "yamd_version", "yamd_init", "yamd_conv_desc_init", "yamd_conv_desc_tune", "yamd_conv_pack_weights", "yamd_conv2d_bias_act", "yamd_conv2d_bias_act_split",
+    "yamd_last_error", "yamd_version", "yamd_init", "yamd_conv_desc_init", "yamd_conv_desc_tune", "yamd_conv_pack_weights", "yamd_conv2d_bias_act", "yamd_conv2d_bias_act_split", "yamd_conv2d_bias_act_cat2",
     "yamd_focus_pack", "yamd_nchw_to_nhwc16", "yamd_upsample2x", "yamd_maxpool2", "yamd_maxpool5_cascade", "yamd_maxpool3_cascade",
     "yamd_copy_channels", "yamd_depth_to_space2", "yamd_decode_ltrb_points",
     "yamd_decode_anchor", "yamd_decode_anchor_levels", "yamd_decode_dfl", "yamd_decode_dfl_unit_conf", "yamd_decode_dfl_points", "yamd_nms_workspace_bytes", "yamd_nms_batched", "yamd_nms_static_capacity_bytes", "yamd_nms_batched_static", "yamd_compact_rows", "yamd_letterbox_workspace_bytes", "yamd_letterbox_u8", "yamd_detect_match", "yamd_stem_packed_elems", "yamd_stem_pack_weights", "yamd_stem_conv", "yamd_stem_conv2_packed_elems", "yamd_stem_conv2_pack_weights", "yamd_stem_conv2",
@@ -27,7 +27,7 @@ EXPORTS = [
 
 # yamd_plan_op.kind
 OP_CONV, OP_CONV_SPLIT, OP_STEM, OP_STEM_CONV2, OP_FOCUS, OP_NHWC16, OP_UPSAMPLE2X, OP_MAXPOOL5_CASCADE, \
-    OP_MAXPOOL3_CASCADE, OP_MAXPOOL2, OP_DEPTH_TO_SPACE2, OP_COPY_CHANNELS = range(1, 13)
+    OP_MAXPOOL3_CASCADE, OP_MAXPOOL2, OP_DEPTH_TO_SPACE2, OP_COPY_CHANNELS, OP_CONV_CAT2 = range(1, 14)
 
 
 class ConvDesc(ctypes.Structure):
@@ -39,7 +39,7 @@ class ConvDesc(ctypes.Structure):
 
 class PlanOp(ctypes.Structure):
     """Mirror of ``yamd_plan_op``."""
-    _fields_ = [("kind", c_int32), ("i", c_int32 * 8), ("p", c_void_p * 7), ("desc", ConvDesc)]
+    _fields_ = [("kind", c_int32), ("i", c_int32 * 9), ("p", c_void_p * 7), ("desc", ConvDesc)]
 
 
 class YamdError(RuntimeError):
@@ -67,6 +67,8 @@ def _load() -> ctypes.CDLL:
                                          c_int, c_int, c_int, c_int, c_void_p]
     lib.yamd_conv2d_bias_act_split.argtypes = [P(ConvDesc), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                                c_int, c_int, c_int, c_int, c_void_p]
+    lib.yamd_conv2d_bias_act_cat2.argtypes = [P(ConvDesc), c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                              c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.yamd_focus_pack.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]
     lib.yamd_nchw_to_nhwc16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
     lib.yamd_upsample2x.argtypes = [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]
