@@ -177,13 +177,9 @@ from yolo_amd.pipeline import HostSink, TwoStreamStep  # noqa: E402
 
 
 def step(model, images, sink):
-    if STEP_IMPL is not None:
-        return STEP_IMPL(images, sink)
+    """One step on the launch stream: the whole path for one batch, then the hand-over of its rows."""
     rows, counts = model.predict_device(images)
     sink.submit(rows, counts)
-
-
-STEP_IMPL = None
 
 
 def stage_profile(model, images, reps=3):
@@ -467,18 +463,20 @@ def main():
     sink = HostSink(B, A, width, dev)
     prog = model.program()
     if args.two_stream:
-        global STEP_IMPL
-        STEP_IMPL = TwoStreamStep(model, dev)
+        two_stream = TwoStreamStep(model, dev)
+        run_step = lambda: two_stream(images, sink)      # noqa: E731
+    else:
+        run_step = lambda: step(model, images, sink)     # noqa: E731
 
     for _ in range(args.warmup):
-        step(model, images, sink)
+        run_step()
     sink.drain()
     spans = []
     prog.span_sink = spans          # conv launches bracketed by events on the launch stream, inside the timed region
     barrier(world, False)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(model, images, sink)
+        run_step()
     sink.drain()                      # the last step's detections are on the host before the clock stops
     barrier(world, False)
     elapsed = max_over_ranks(time.perf_counter() - t0, world, False)
