@@ -167,6 +167,36 @@ def test_every_family_and_width_compiles():
             assert len(prog.convs) > 40 and len(prog.outputs) == len(p.strides), (cls.__name__, t)
 
 
+def test_upsample_cat_rewrite_of_the_recorded_ops():
+    """Program.fuse_upsample_cat on the host: every 2x upsampling whose readers are 1x1 convs over [upsampled | other]
+    disappears and its readers become conv_cat2 ops over the low-resolution view and the other part; the conv count,
+    the MAC count and the outputs do not change; a reader that is not a 1x1 conv keeps the upsampling."""
+    import torch
+    from yolo_amd import engine, lib as L, models
+    for name, n_cat2 in (("v5s", 2), ("v8s", 2), ("v3", 2), ("v7pose", 4), ("v6face", 0)):
+        p, m = models.create(name, img_size=128)
+        prog = m.program()
+        ups = [op for op in prog.ops if op[0] == "up2"]
+        convs, macs = prog.n_conv_launches(), prog.conv_macs_per_image()
+        assert prog.fuse_upsample_cat() == len(ups)
+        assert not any(op[0] == "up2" for op in prog.ops)
+        cat2 = [op for op in prog.ops if op[0] == "conv_cat2"]
+        assert len(cat2) == n_cat2 and prog.n_conv_launches() == convs and prog.conv_macs_per_image() == macs
+        for _, layer, xa, a_half, xb, b_half, out, out2 in cat2:
+            low, full = (xa, xb) if a_half else (xb, xa)
+            assert a_half != b_half and (low.h * 2, low.w * 2) == (full.h, full.w) == (out.h, out.w)
+            assert xa.c + xb.c == layer.desc.cin and xa.c % layer.desc.ck == 0 and xb.c % layer.desc.ck == 0
+        assert prog.fuse_upsample_cat() == 0          # nothing left to do
+    # a 3x3 reader: the upsampling stays
+    prog = engine.Program(64, 64)
+    x = prog.image16()
+    a = prog.conv("a", x, torch.zeros(32, 16, 1, 1), None, 1, L.ACT_NONE)
+    low = prog.conv("low", prog.maxpool2(a), torch.zeros(32, 32, 1, 1), None, 1, L.ACT_NONE)
+    cat = prog.cat([prog.upsample2x(low), a])
+    prog.conv("reader", cat, torch.zeros(32, 64, 3, 3), None, 1, L.ACT_NONE)
+    assert prog.fuse_upsample_cat() == 0 and any(op[0] == "up2" for op in prog.ops)
+
+
 def test_plan_follows_weights_loaded_through_a_submodule():
     """The compiled plan is keyed on the parameters themselves: loading weights into a submodule (the way the reference
     loads a pretrained backbone), changing a tensor in place or changing the Param fields the plan reads all give a
