@@ -186,6 +186,15 @@ constexpr int F_IFRAG = (F_IPIX + 31) / 32;
 constexpr int F_HALF = (F_IC + 1) / 2;                      // a row of stem pixels is stored even columns first, then odd:
 constexpr int F_CROW = 2 * F_HALF;                          // the stride-2 taps of neighbouring outputs are neighbours in LDS
 
+// Tile counters of the fused launches: a ring of 256 per GPU, each launch zeroes and uses the next one (on its stream), so
+// launches that overlap on one GPU -- other streams, other host threads -- do not share a counter unless 256 of them are
+// in flight at once.  The array's name is a host-side handle only; every device has its own copy at its own address.
+constexpr int TICKET_RING = 256;
+constexpr int TICKET_MAX_DEVICES = 64;
+std::atomic<unsigned *> g_ticket_base[TICKET_MAX_DEVICES];
+std::atomic<unsigned> g_ticket_seq{0};
+int next_ticket(unsigned **out);
+
 template <int KS, int S>
 struct FusedGeom {
     static constexpr int PAD = KS == 6 ? 2 : 1;
@@ -211,6 +220,7 @@ struct FusedParams {
     const float *b2;
     __bf16 *y;
     int H, W, H1, W1, H2, W2, C2, y_cs, act1, act2, tiles_x, tiles_y, total_tiles;
+    unsigned *ticket;      // zero at launch: tiles after a workgroup's first are handed out by this counter
 };
 
 // SILU: both activations are SiLU (compile-time, the usual case); otherwise they are looked up per value
@@ -291,11 +301,16 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
     const int pr = wm * 2 + (c32 >> 4), pc = c32 & 15;
     const int pixbase = ((2 * pr) * F_CROW + pc) * RS2 + g * 16;
 
-    const int tile_step = gridDim.x;
+    // A workgroup's first tile is its index; further tiles are handed out by a counter, so a workgroup that shares
+    // its compute unit with other work (a copy kernel, another stream) takes fewer tiles instead of holding the launch
+    // up with a fixed share.  Thread 0 draws the ticket one tile ahead, so its latency is never waited for.
+    int *s_next = (int *)(w2s + W2_BYTES);
     int tile = blockIdx.x;
     if (tile >= p.total_tiles) return;
+    int ticket = 0;
+    if (tid == 0) ticket = (int)gridDim.x + (int)atomicAdd(p.ticket, 1u);
     load_patch(tile);
-    for (; tile < p.total_tiles; tile += tile_step) {
+    for (;;) {
         int t = tile;
         const int tx = t % p.tiles_x;
         t /= p.tiles_x;
@@ -315,8 +330,11 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
             }
         }
         if (tid < 8) patch[G::PATCH + tid] = (__bf16)0.0f;
+        if (tid == 0) *s_next = ticket;
         __syncthreads();
-        if (tile + tile_step < p.total_tiles) load_patch(tile + tile_step);      // in flight during this tile's MFMAs
+        const int next = *s_next;
+        if (tid == 0) ticket = (int)gridDim.x + (int)atomicAdd(p.ticket, 1u);
+        if (next < p.total_tiles) load_patch(next);      // in flight during this tile's MFMAs
 
         // ---- stem on the 9 x 33 pixels under the tile, 32 at a time
         for (int f = wave; f < F_IFRAG; f += 4) {
@@ -419,6 +437,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
                 *(uint4 *)(p.y + ((b * p.H2 + oh) * p.W2 + ow) * p.y_cs + co) = *(const uint4 *)(stage + fp * RSO + piece * 16);
         }
         __syncthreads();                                      // the next tile's patch overwrites the output tile
+        if (next >= p.total_tiles) break;
+        tile = next;
     }
 }
 
@@ -429,7 +449,7 @@ int launch_stem_conv2_act(const FusedParams &p, hipStream_t st)
     constexpr int C1 = NREP1 * 32, RS2 = C1 * 2 + 16, RSO = NREP2 * 64 + 16;
     constexpr int PATCH_BYTES = ((G::PATCH + 8) * 2 + 15) / 16 * 16, STAGE_BYTES = 64 * RSO;
     constexpr int A_BYTES = PATCH_BYTES > STAGE_BYTES ? PATCH_BYTES : STAGE_BYTES;
-    constexpr size_t LDS = (size_t)A_BYTES + (size_t)F_IR * F_CROW * RS2 + (size_t)9 * (C1 / 16) * NREP2 * 1024;
+    constexpr size_t LDS = (size_t)A_BYTES + (size_t)F_IR * F_CROW * RS2 + (size_t)9 * (C1 / 16) * NREP2 * 1024 + 16;
     static_assert(LDS <= 160 * 1024, "fused stem tile does not fit LDS");
     auto kern = stem_conv2_kernel<KS, S, NREP1, NREP2, SILU>;
     {
@@ -445,7 +465,13 @@ int launch_stem_conv2_act(const FusedParams &p, hipStream_t st)
     if (per_cu < 1) per_cu = 1;
     long long grid = (long long)cus * per_cu;
     if (grid > p.total_tiles) grid = p.total_tiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, st, p);
+    FusedParams q = p;
+    {
+        const int rc = next_ticket(&q.ticket);
+        if (rc != YAMD_OK) return rc;
+    }
+    YAMD_HIP(hipMemsetAsync(q.ticket, 0, sizeof(unsigned), st));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, st, q);
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
 }
@@ -455,6 +481,28 @@ int launch_stem_conv2(const FusedParams &p, hipStream_t st)
 {
     if (p.act1 == YAMD_ACT_SILU && p.act2 == YAMD_ACT_SILU) return launch_stem_conv2_act<KS, S, NREP1, NREP2, true>(p, st);
     return launch_stem_conv2_act<KS, S, NREP1, NREP2, false>(p, st);
+}
+
+}  // namespace
+
+static __device__ __align__(256) unsigned stem_tickets[256];
+
+namespace {
+int next_ticket(unsigned **out)
+{
+    int dev = 0;
+    YAMD_HIP(hipGetDevice(&dev));
+    YAMD_REQUIRE(dev >= 0 && dev < TICKET_MAX_DEVICES, "device ordinal %d outside [0, %d)", dev, TICKET_MAX_DEVICES);
+    unsigned *base = g_ticket_base[dev].load(std::memory_order_acquire);
+    if (base == nullptr) {
+        void *ptr = nullptr;
+        YAMD_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(stem_tickets)));   // this device's copy (the device is current)
+        YAMD_REQUIRE(ptr != nullptr, "tile counters have no device address");
+        base = (unsigned *)ptr;
+        g_ticket_base[dev].store(base, std::memory_order_release);
+    }
+    *out = base + (g_ticket_seq.fetch_add(1u, std::memory_order_relaxed) % TICKET_RING);
+    return YAMD_OK;
 }
 
 bool stem_mode(int mode, int &ks, int &s)
@@ -582,6 +630,7 @@ extern "C" int yamd_stem_conv2(int mode, const float *images, int batch, int h, 
                      ((uintptr_t)w2_packed % 16) == 0 && ((uintptr_t)b1_packed % 16) == 0 && ((uintptr_t)b2_packed % 16) == 0,
                  "fused stem output / weights need 16-byte alignment (cstride=%d)", y_cstride);
     FusedParams p;
+    p.ticket = nullptr;      // set per launch
     p.img = images;
     p.w1 = (const bf16x8 *)w1_packed;
     p.b1 = b1_packed;
