@@ -3,7 +3,7 @@
 // built by scratch/conv_ablate.py
 #include "yamd_conv_kernel.h"
 using namespace yamd;
-namespace yamd { int nms_init_current_device(int) { return 0; } }
+namespace yamd { int nms_init_current_device(int) { return 0; } int stem_init_current_device(int) { return 0; } }
 
 extern "C" int conv_ablate_run(const void *x, int x_cs, const void *w, const float *bias, void *y, int y_cs, int batch,
                                int h, int wd, int cin, int cout)

@@ -2,7 +2,7 @@
 // hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -shared -DYAMD_CONV_TRACE -I../yolo_amd/csrc -I../include conv_trace.hip ../yolo_amd/csrc/yamd_core.hip -o libconv_trace.so
 #include "yamd_conv_kernel.h"
 using namespace yamd;
-namespace yamd { int nms_init_current_device(int) { return 0; } }
+namespace yamd { int nms_init_current_device(int) { return 0; } int stem_init_current_device(int) { return 0; } }
 
 #ifndef TR_KS
 #define TR_KS 1

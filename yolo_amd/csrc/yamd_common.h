@@ -67,5 +67,7 @@ struct KernelAttr {
 
 // per-device set-up of the NMS kernels and their static scratch array (yamd_nms.hip), called by yamd_init
 int nms_init_current_device(int device);
+// resolves the address of the fused stem's tile counters on the current device (yamd_stem.hip), called by yamd_init
+int stem_init_current_device(int device);
 
 }  // namespace yamd

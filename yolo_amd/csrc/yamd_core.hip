@@ -71,7 +71,8 @@ extern "C" int yamd_init(void)
         const int rc = raise_dynamic_lds(*e.once, e.kernel, e.lds_bytes);
         if (rc != YAMD_OK) return rc;
     }
-    return nms_init_current_device(dev);
+    const int rc = nms_init_current_device(dev);
+    return rc != YAMD_OK ? rc : stem_init_current_device(dev);
 }
 
 namespace {

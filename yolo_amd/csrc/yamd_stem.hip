@@ -505,6 +505,18 @@ int next_ticket(unsigned **out)
     return YAMD_OK;
 }
 
+}  // namespace
+
+namespace yamd {
+int stem_init_current_device(int device)
+{
+    (void)device;
+    unsigned *t = nullptr;
+    return next_ticket(&t);
+}
+}  // namespace yamd
+
+namespace {
 bool stem_mode(int mode, int &ks, int &s)
 {
     switch (mode) {
