@@ -173,17 +173,24 @@ __global__ __launch_bounds__(256) void nms_bucket_kernel(NmsParams p)
 }
 
 // suppression test of the torchvision CPU kernel: i = kept (higher score) box, j = candidate
-__device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy2, float ia, float jx1, float jy1,
-                                       float jx2, float jy2, float ja, float thr)
+__device__ __forceinline__ float iou_inter(float ix1, float iy1, float ix2, float iy2, float jx1, float jy1, float jx2, float jy2)
 {
     const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1);
     const float xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
     const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
-    const float inter = w * h;
+    return w * h;
+}
+__device__ __forceinline__ bool iou_ratio_gt(float inter, float ia, float ja, float thr)
+{
     float uni = ia + ja;
     uni = uni - inter;
     const float ovr = inter / uni;
     return ovr > thr;
+}
+__device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy2, float ia, float jx1, float jy1,
+                                       float jx2, float jy2, float ja, float thr)
+{
+    return iou_ratio_gt(iou_inter(ix1, iy1, ix2, iy2, jx1, jy1, jx2, jy2), ia, ja, thr);
 }
 
 constexpr int SEG_THREADS = 1024;           // 16 waves per bucket
@@ -615,7 +622,11 @@ __global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
                         const int k = __ffsll((long long)rel) - 1;
                         rel &= rel - 1ull;
                         const float4 qb = kb[k];
-                        sup = sup || iou_gt(qb.x, qb.y, qb.z, qb.w, ka[k], jx.x, jx.y, jx.z, jx.w, ja, p.iou_thr);
+                        // a kept box that touches the group's bounding box but none of its boxes: no lane has an
+                        // intersection, and a zero intersection never suppresses (the threshold is >= 0): skip the division
+                        const float inter = iou_inter(qb.x, qb.y, qb.z, qb.w, jx.x, jx.y, jx.z, jx.w);
+                        if (__ballot(inter > 0.0f) == 0ull) continue;
+                        sup = sup || iou_ratio_gt(inter, ka[k], ja, p.iou_thr);
                     }
                     const u64 sm = __ballot(sup && todo);
                     if (lane == 0 && sm) atomicOr(&rem[g], sm);
@@ -637,7 +648,11 @@ __global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
                         const int k = __ffsll((long long)rel) - 1;
                         rel &= rel - 1ull;
                         const float4 qb = kb[k];
-                        sup = sup || iou_gt(qb.x, qb.y, qb.z, qb.w, ka[k], jx.x, jx.y, jx.z, jx.w, ja, p.iou_thr);
+                        // a kept box that touches the group's bounding box but none of its boxes: no lane has an
+                        // intersection, and a zero intersection never suppresses (the threshold is >= 0): skip the division
+                        const float inter = iou_inter(qb.x, qb.y, qb.z, qb.w, jx.x, jx.y, jx.z, jx.w);
+                        if (__ballot(inter > 0.0f) == 0ull) continue;
+                        sup = sup || iou_ratio_gt(inter, ka[k], ja, p.iou_thr);
                     }
                     const u64 sm = __ballot(sup && todo);
                     if (lane == 0 && sm) atomicOr(&rem[g], sm);
