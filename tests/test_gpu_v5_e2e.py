@@ -122,6 +122,34 @@ def test_v5s_640_vs_oracle_graph(gpu_device):
     _check_pred(pred[:1, g["pred_rows"]], g["pred"], 640)
 
 
+def test_v5s_1280_vs_oracle_graph(gpu_device):
+    """The largest input the reference's scripts use, 1280 x 1280, one image: 100 800 anchors, a 40 x 40 SPP plane, layer
+    shapes without measured tilings.  Head logits and decoded tensor against the fp32 CPU oracle graph on the same
+    weights; NMS on the GPU's own decoded tensor equal to the C-oracle NMS on it, bit for bit."""
+    from oracle import decode_ref, postprocess as pp, v5_ref
+    from yolo_amd import torch_utils as tu
+    from yolo_amd.init import seeded_images, seeded_state_dict
+    p, m = _model(1280, 77, gpu_device)
+    sd = seeded_state_dict(m, seed=77, mode="spread")
+    imgs_np = seeded_images(1, 1280, seed=77)
+    imgs = torch.from_numpy(imgs_np).to(gpu_device)
+    raws = [r.cpu().numpy().transpose(0, 3, 1, 2) for r in m.raw_heads(imgs)]
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        want_raws = [t.numpy() for t in v5_ref.body_forward(sd, torch.from_numpy(imgs_np))]
+    for got, want, name in zip(raws, want_raws, ("P3", "P4", "P5")):
+        assert got.shape == want.shape and _rel_l2(got, want) <= 3e-2, (name, _rel_l2(got, want))
+    pred_dev = m._forward(imgs)[0]
+    pred = pred_dev.cpu().numpy()
+    assert pred.shape == (1, 100800, 25)
+    _check_pred(pred, decode_ref.decode_anchor(want_raws, p.anchors, p.strides, 1280, "v5"), 1280)
+    rows, counts, _ = tu.nms_batched(pred_dev, 1280, "cxcywh", p.conf_threshold, p.nms_threshold)
+    want_rows = pp.non_max_suppression(pred, 1280, "cxcywh", p.conf_threshold, p.nms_threshold)[0]
+    k = int(counts.cpu()[0])
+    assert want_rows is not None and k == want_rows.shape[0] and k > 0
+    assert np.array_equal(rows[0, :k].cpu().numpy().view(np.uint32), want_rows.view(np.uint32))
+
+
 def test_full_batch_properties(gpu_device):
     """Benchmark size (B=256, 640x640, 25200 anchors): size-independent properties of the whole path."""
     from oracle import postprocess as pp
