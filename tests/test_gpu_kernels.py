@@ -103,6 +103,12 @@ CONV_CASES = [
     (3, 2, 48, 96, 32, 32, 1, False, False),
     (1, 1, 80, 75, 20, 20, 0, False, True),
     (1, 1, 96, 75, 16, 16, 0, False, True),
+    # narrow float heads (box sides, one class score, landmarks): one 32-column group, element-parallel slice stores
+    (1, 1, 64, 4, 20, 20, 0, False, True),
+    (1, 1, 64, 1, 17, 23, 0, False, True),
+    (1, 1, 128, 10, 40, 40, 0, False, True),
+    (1, 1, 48, 32, 10, 10, 0, False, True),
+    (1, 1, 96, 17, 12, 20, 0, False, True),
 ]
 
 

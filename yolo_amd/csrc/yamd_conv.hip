@@ -50,7 +50,7 @@ extern "C" int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int
     d->residual_scale = 1.0f;
     if (out_f32) {
         YAMD_REQUIRE(ksize == 1, "float output is only built for 1x1 convs");
-        d->nrep = 4;
+        d->nrep = groups == 1 ? 1 : 4;       // a head with at most 32 outputs (box sides, one class, landmarks): one column group
         d->ck = cin % 64 == 0 ? 64 : (cin % 32 == 0 ? 32 : 16);
     } else if (ksize == 1) {
         YAMD_REQUIRE(cin % 16 == 0, "1x1 conv needs cin %% 16 == 0 (got %d)", cin);

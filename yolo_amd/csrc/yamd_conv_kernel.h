@@ -460,6 +460,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
                             *(f32x4 *)((float *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs +
                                        nt * (NREP * 32) + piece * 4) = *(const f32x4 *)(wreg + r * RSF + piece * 16);
                     }
+                } else if (nco < 32) {
+                    // a narrow slice (the 4 box sides, 1 class score or 10 landmark values of an anchor-free head written
+                    // next to each other in one row): lanes walk (pixel, channel) pairs, so a wave instruction stores 64
+                    // values instead of the nco of one pixel
+                    const float invn = 1.0f / (float)nco;
+                    for (int i = lane; i < 32 * nco; i += 64) {
+                        const int r = (int)(((float)i + 0.5f) * invn);
+                        const int c = i - r * nco;
+                        const int pq = wave * (32 * MREP) + m * 32 + r;
+                        const int qr = pq / TW, qc = pq % TW;
+                        if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)
+                            ((float *)p.y)[((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + nt * (NREP * 32) + c] =
+                                *(const float *)(wreg + r * RSF + c * 4);
+                    }
                 } else {
                     for (int r = 0; r < 32; ++r) {
                         const int pq = wave * (32 * MREP) + m * 32 + r;

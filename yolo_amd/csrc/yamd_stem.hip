@@ -223,8 +223,9 @@ struct FusedParams {
     unsigned *ticket;      // zero at launch: tiles after a workgroup's first are handed out by this counter
 };
 
-// SILU: both activations are SiLU (compile-time, the usual case); otherwise they are looked up per value
-template <int KS, int S, int NREP1, int NREP2, bool SILU>
+// ACTK >= 0: both activations are that kind, fixed at compile time (SiLU for v5 / v8, ReLU for the re-parameterised v6
+// stems); ACTK < 0: they are looked up per value
+template <int KS, int S, int NREP1, int NREP2, int ACTK>
 __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
 {
     using G = FusedGeom<KS, S>;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             bias2[q][i] = *(const f32x4 *)(p.b2 + min((wave >> 1) + 2 * q, NREP2 - 1) * 32 + 8 * i + 4 * g);
-    const int act1 = SILU ? YAMD_ACT_SILU : p.act1, act2 = SILU ? YAMD_ACT_SILU : p.act2;
+    const int act1 = ACTK >= 0 ? ACTK : p.act1, act2 = ACTK >= 0 ? ACTK : p.act2;
 
     // The patch is loaded two columns at a time: its first column is even in the image (XO below) and so is its width,
     // so a pair is 8-byte aligned and lies inside the image or outside it as a whole.
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
     }
 }
 
-template <int KS, int S, int NREP1, int NREP2, bool SILU>
+template <int KS, int S, int NREP1, int NREP2, int ACTK>
 int launch_stem_conv2_act(const FusedParams &p, hipStream_t st)
 {
     using G = FusedGeom<KS, S>;
@@ -451,9 +452,9 @@ int launch_stem_conv2_act(const FusedParams &p, hipStream_t st)
     constexpr int A_BYTES = PATCH_BYTES > STAGE_BYTES ? PATCH_BYTES : STAGE_BYTES;
     constexpr size_t LDS = (size_t)A_BYTES + (size_t)F_IR * F_CROW * RS2 + (size_t)9 * (C1 / 16) * NREP2 * 1024 + 16;
     static_assert(LDS <= 160 * 1024, "fused stem tile does not fit LDS");
-    auto kern = stem_conv2_kernel<KS, S, NREP1, NREP2, SILU>;
+    auto kern = stem_conv2_kernel<KS, S, NREP1, NREP2, ACTK>;
     {
-        const int rc = KernelAttr<&stem_conv2_kernel<KS, S, NREP1, NREP2, SILU>, 160 * 1024>::ensure();
+        const int rc = KernelAttr<&stem_conv2_kernel<KS, S, NREP1, NREP2, ACTK>, 160 * 1024>::ensure();
         if (rc != YAMD_OK) return rc;
     }
     // persistent grid: the workgroups resident at once share the tiles; each keeps the second conv's weights in LDS
@@ -479,8 +480,9 @@ int launch_stem_conv2_act(const FusedParams &p, hipStream_t st)
 template <int KS, int S, int NREP1, int NREP2>
 int launch_stem_conv2(const FusedParams &p, hipStream_t st)
 {
-    if (p.act1 == YAMD_ACT_SILU && p.act2 == YAMD_ACT_SILU) return launch_stem_conv2_act<KS, S, NREP1, NREP2, true>(p, st);
-    return launch_stem_conv2_act<KS, S, NREP1, NREP2, false>(p, st);
+    if (p.act1 == YAMD_ACT_SILU && p.act2 == YAMD_ACT_SILU) return launch_stem_conv2_act<KS, S, NREP1, NREP2, YAMD_ACT_SILU>(p, st);
+    if (p.act1 == YAMD_ACT_RELU && p.act2 == YAMD_ACT_RELU) return launch_stem_conv2_act<KS, S, NREP1, NREP2, YAMD_ACT_RELU>(p, st);
+    return launch_stem_conv2_act<KS, S, NREP1, NREP2, -1>(p, st);
 }
 
 }  // namespace
