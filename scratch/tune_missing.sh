@@ -1,0 +1,12 @@
+#!/bin/bash
+# measure the tilings of layer shapes the table lacks: usage tune_missing.sh "v4 256" "v7pose 512" ...; result in gpurun_out/tuned_gfx950.json
+set -e
+R=$GRAFT_REPO_ROOT
+cd $R
+cp yolo_amd/tuned_gfx950.json gpurun_out/tuned_gfx950.json
+for spec in "$@"; do
+  set -- $spec
+  echo "== $1 batch $2"
+  YAMD_TUNING_TABLE=$R/gpurun_out/tuned_gfx950.json timeout -k 10 400 python -u -m yolo_amd.tuning --model $1 --batch $2 --reps 8 --missing-only --out $R/gpurun_out/tuned_gfx950.json > gpurun_out/tune_missing_$1.log 2>&1
+  tail -1 gpurun_out/tune_missing_$1.log
+done

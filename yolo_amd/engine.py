@@ -348,9 +348,9 @@ class Program:
         return buf, coff
 
     # ---- per-layer tiling search ------------------------------------------------------------------
-    def autotune(self, batch: int, device, reps: int = 5, log=None) -> Dict[str, Tuple[int, ...]]:
+    def autotune(self, batch: int, device, reps: int = 5, log=None, skip=()) -> Dict[str, Tuple[int, ...]]:
         """Times every built tiling of every bf16 conv on this program's own buffers and keeps the fastest.
-        Returns {tuning key: (mrep, nrep, ck)} for ``tuning.save``."""
+        Returns {tuning key: (mrep, nrep, ck)} for ``tuning.save``; layer shapes whose key is in ``skip`` keep their tiling."""
         from . import tuning
         bufs = self._buffers_for(batch, device)
         st = _lib.current_stream()
@@ -362,6 +362,8 @@ class Program:
             k, s = layer._args[0], layer._args[1]
             cout = out.c + (out2.c if out2 is not None else 0)
             key = tuning.key(k, s, x.c, cout, out.h, out.w)
+            if key in skip:
+                continue
             if key in best:
                 layer.pack(best[key])
                 layer.to(device)

@@ -68,9 +68,13 @@ def main() -> None:
     ap.add_argument("--out", default=PATH)
     ap.add_argument("--reps", type=int, default=10, help="timed launches per candidate")
     ap.add_argument("--in-situ", action="store_true", help="time candidates inside whole-program runs (realistic cache state)")
+    ap.add_argument("--missing-only", action="store_true", help="measure only the layer shapes the table does not hold yet")
     args = ap.parse_args()
     global enabled
-    if not args.in_situ:
+    if args.missing_only:
+        from . import engine
+        engine.FUSE["upsample_cat"] = False            # their readers are measured as plain convs of the same shape
+    elif not args.in_situ:
         enabled = False                                # start every layer from the default rule
     p, m = models.create(args.model)
     dev = torch.device("cuda", 0)
@@ -80,7 +84,7 @@ def main() -> None:
     if args.in_situ:
         best = prog.autotune_in_situ(imgs, reps=args.reps, log=print)
     else:
-        best = prog.autotune(args.batch, dev, reps=args.reps, log=print)
+        best = prog.autotune(args.batch, dev, reps=args.reps, log=print, skip=set(table()) if args.missing_only else ())
     save(best, args.out)
     print(f"{len(best)} layer shapes -> {args.out}")
 

@@ -6,12 +6,13 @@ SpatialPyramidPooling :151-162 in the order [13, 9, 5, x], YoloV4BackBone.forwar
 keys are identical.  BatchNorm uses torch's default eps 1e-5.  ``fuse()`` folds the backbone's BasicConv blocks
 only, like the reference (YoloV4.py:216-221).
 """
+import torch
 import torch.nn as nn
 
 from . import lib as _lib
 from . import torch_utils
 from .engine import Program, View
-from .graph import AnchorTaskModel, Recorder
+from .graph import AnchorTaskModel, Recorder, folded
 from .param import Yolo4Param
 from .yolov3 import _cbl, _seq
 
@@ -98,14 +99,22 @@ class YoloV4(AnchorTaskModel):
         for i, st in enumerate(bb.stages):
             n = f"stages.{i}"
             x = M.cba(f"{n}.downsample_conv", st.downsample_conv, x)
-            x0 = M.cba(f"{n}.split_conv0", st.split_conv0, x)
-            x1 = M.cba(f"{n}.split_conv1", st.split_conv1, x)
+            # split_conv0 and split_conv1 read the same input: ONE conv computes both (one read of x, one launch), its
+            # couts [0, h) = split_conv0 go to the second half of the concat buffer, [h, 2h) = split_conv1 to a buffer of
+            # their own (the residual chain works on it); the chain's last conv fills the first half
+            w0, b0, _ = folded(st.split_conv0)
+            w1, b1, _ = folded(st.split_conv1)
+            h = w0.shape[0]
+            catb = P.buffer(x.h, x.w, 2 * h)
+            x1 = P.buffer(x.h, x.w, h)
+            P.conv(f"{n}.split_conv0+1", x, torch.cat((w0, w1), 0), torch.cat((b0, b1), 0), 1, _lib.ACT_MISH,
+                   out=catb.slice(h, h), out2=x1)
             mods = list(st.blocks_conv.children())
             for j, r in enumerate(mods[:-1]):
                 t = M.cba(f"{n}.blocks_conv.{j}.block.0", getattr(r.block, "0"), x1)
                 x1 = M.cba(f"{n}.blocks_conv.{j}.block.1", getattr(r.block, "1"), t, residual=x1)
-            x1 = M.cba(f"{n}.blocks_conv.{len(mods) - 1}", mods[-1], x1)
-            x = M.cba(f"{n}.concat_conv", st.concat_conv, P.cat([x1, x0]))
+            M.cba(f"{n}.blocks_conv.{len(mods) - 1}", mods[-1], x1, out=catb.slice(0, h))
+            x = M.cba(f"{n}.concat_conv", st.concat_conv, catb)
             feats.append(x)
         x2, x1, x0 = feats[2], feats[3], feats[4]
 

@@ -132,10 +132,25 @@ class YoloV7Pose(AnchorTaskModel):
     # ---- graph -----------------------------------------------------------------------------------
     @staticmethod
     def _mcb(R: Recorder, name: str, m: nn.Module, x: View) -> View:
-        xs = [R.cba(f"{name}.cv1", m.cv1, x), R.cba(f"{name}.cv2", m.cv2, x)]
+        n = 2 + len(m.cv3)
+        ids = [i % n for i in m.ids]
+        if ids[-2:] != [1, 0]:
+            xs = [R.cba(f"{name}.cv1", m.cv1, x), R.cba(f"{name}.cv2", m.cv2, x)]
+            for i, cv in enumerate(m.cv3):
+                xs.append(R.cba(f"{name}.cv3.{i}", cv, xs[-1]))
+            return R.cba(f"{name}.cv4", m.cv4, R.p.cat([xs[i] for i in ids]))
+        # cv1 and cv2 are 1x1 convs of the same input whose outputs end the concat as [.., cv2, cv1]: they run as one
+        # conv that reads the input once and writes both slices
+        (w1, b1, _), (w2, b2, _) = folded(m.cv1), folded(m.cv2)
+        c_, c2 = w1.shape[0], m.cv3[0].conv.out_channels
+        cat = R.p.buffer(x.h, x.w, 2 * c_ + c2 * (len(ids) - 2))
+        place = {j: cat.slice(k * c2, c2) for k, j in enumerate(ids[:-2])}
+        tail = cat.slice(c2 * (len(ids) - 2), 2 * c_)
+        R.p.conv(f"{name}.cv2+1", x, torch.cat((w2, w1), 0), torch.cat((b2, b1), 0), 1, R.act, out=tail)
+        t = tail.slice(0, c_)
         for i, cv in enumerate(m.cv3):
-            xs.append(R.cba(f"{name}.cv3.{i}", cv, xs[-1]))
-        return R.cba(f"{name}.cv4", m.cv4, R.p.cat([xs[i] for i in m.ids]))
+            t = R.cba(f"{name}.cv3.{i}", cv, t, out=place.get(2 + i))
+        return R.cba(f"{name}.cv4", m.cv4, cat)
 
     @staticmethod
     def _transition(R: Recorder, name: str, m: nn.Module, x: View) -> View:
@@ -172,12 +187,16 @@ class YoloV7Pose(AnchorTaskModel):
         sp = body.spp_csp_c
         c_ = sp.cv4.conv.out_channels
         cat = P.buffer(feat3.h, feat3.w, 4 * c_, name="cat_spp")
-        t = R.cba("spp.cv3", sp.cv3, R.cba("spp.cv1", sp.cv1, feat3))
+        # cv1 and cv2 both read feat3: one conv, cv1's half to a buffer of its own, cv2's half into cv7's concat input
+        (w1, b1, _), (w2, b2, _) = folded(sp.cv1), folded(sp.cv2)
+        cat7 = P.buffer(feat3.h, feat3.w, 2 * c_, name="cat_spp_out")
+        t = P.buffer(feat3.h, feat3.w, c_)
+        P.conv("spp.cv1+2", feat3, torch.cat((w1, w2), 0), torch.cat((b1, b2), 0), 1, R.act, out=t, out2=cat7.slice(c_, c_))
+        t = R.cba("spp.cv3", sp.cv3, t)
         R.cba("spp.cv4", sp.cv4, t, out=cat.slice(0, c_))
         P.maxpool5_cascade(cat.slice(0, c_), cat.slice(c_, c_), cat.slice(2 * c_, c_), cat.slice(3 * c_, c_))
-        y1 = R.cba("spp.cv6", sp.cv6, R.cba("spp.cv5", sp.cv5, cat))
-        y2 = R.cba("spp.cv2", sp.cv2, feat3)
-        p5 = R.cba("spp.cv7", sp.cv7, P.cat([y1, y2]))
+        R.cba("spp.cv6", sp.cv6, R.cba("spp.cv5", sp.cv5, cat), out=cat7.slice(0, c_))
+        p5 = R.cba("spp.cv7", sp.cv7, cat7)
 
         up = P.upsample2x(R.cba("conv_for_P5", body.conv_for_P5, p5))
         p4 = self._mcb(R, "conv3_for_up_sample1", body.conv3_for_up_sample1,
