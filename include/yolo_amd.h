@@ -314,6 +314,23 @@ int yamd_stem_conv2(int mode, const float *images, int batch, int h, int w, cons
                     int act2, void *y, int y_cstride, void *stream);
 
 /* ----------------------------------------------------------------------------------------
+ * A residual bottleneck in one launch: y = [x +] act(conv3x3(act(conv1x1(x)))), i.e. `x + self.cv2(self.cv1(x))` of
+ * Bottleneck (yolov5/YoloV5Body.py Bottleneck.forward), the residual unit of DarkNet53 (yolov3/DarkNet53.py:33-47:
+ * conv 1x1 to half the channels, conv 3x3 back, `x += residual`) and CSPDarkNet's Resblock (yolov4/YoloV4BackBone.py).
+ * Same result as yamd_conv2d_bias_act twice (the 1x1 conv's output rounded to bf16 in both, the second call with x as
+ * its residual), but that intermediate tensor is neither written nor read back and x is read once.
+ * Built for cin = cout with (cin, cmid) in {(32,32), (64,64), (64,32), (128,128), (128,64)}; both convs stride 1 with
+ * the same activation.  w1: (cmid, cin, 1, 1), w2: (cout, cmid, 3, 3) fp32 with BN folded; the pack call writes
+ * yamd_bottleneck_packed_elems() bf16 values and cmid + cout floats.  shortcut != 0 adds x.  x and y are NHWC bf16,
+ * disjoint tensors or different channel slices of one buffer.
+ * ---------------------------------------------------------------------------------------- */
+int64_t yamd_bottleneck_packed_elems(int cin, int cmid, int cout);   /* 0 = this shape is not built */
+int yamd_bottleneck_pack_weights(int cin, int cmid, int cout, const float *w1_host, const float *b1_host,
+                                 const float *w2_host, const float *b2_host, void *w_packed_host, float *bias_packed_host);
+int yamd_bottleneck(int cin, int cmid, int cout, int act, const void *x, int x_cstride, const void *w_packed,
+                    const float *bias_packed, int shortcut, void *y, int y_cstride, int batch, int h, int w, void *stream);
+
+/* ----------------------------------------------------------------------------------------
  * A model's whole conv graph as one call.  Replaces `out5, out4, out3 = self.body_net(images)`, the module-by-module
  * forward of the backbone + neck + head convs (yolov5/YoloV5.py:54 and :79 over yolov5/YoloV5Body.py:159-187,
  * :223-260; the same statement in every other model class), for callers that do not want one foreign call per layer.
@@ -340,8 +357,9 @@ enum {
     YAMD_OP_MAXPOOL2 = 10,        /* yamd_maxpool2: i = {x_cstride, y_cstride, h, w, c} */
     YAMD_OP_DEPTH_TO_SPACE2 = 11, /* yamd_depth_to_space2: i = {x_cstride, y_cstride, h, w, c (of the output)} */
     YAMD_OP_COPY_CHANNELS = 12,   /* yamd_copy_channels over batch*h*w pixels: i = {x_cstride, y_cstride, h, w, c} */
-    YAMD_OP_CONV_CAT2 = 13        /* yamd_conv2d_bias_act_cat2: desc; p[0] = xa, p[3] = xb, p[5] = y2 or NULL;
+    YAMD_OP_CONV_CAT2 = 13,       /* yamd_conv2d_bias_act_cat2: desc; p[0] = xa, p[3] = xb, p[5] = y2 or NULL;
                                    * i = {xa_cstride, xb_cstride, y_cstride, h, w, y2_cstride, split_cout, ca, xa_half | xb_half << 1} */
+    YAMD_OP_BOTTLENECK = 14       /* yamd_bottleneck: i = {x_cstride, cin, y_cstride, h, w, cmid, cout, act, shortcut} */
 };
 typedef struct yamd_plan_op {
     int32_t kind;

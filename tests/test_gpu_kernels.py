@@ -616,3 +616,52 @@ def test_stem_conv_from_image(gpu_device, mode, cout, H, W, act):
     err = (got - want).abs()
     tol = 2e-2 + 1e-2 * want.abs()          # bf16 output rounding
     assert (err <= tol).all(), f"max err {err.max()} at {want.flatten()[err.argmax()]}"
+
+
+@pytest.mark.parametrize("cin,cmid,H,W,act,shortcut,batch", [
+    (32, 32, 160, 160, 1, 1, 2), (64, 64, 80, 80, 1, 1, 2), (128, 128, 40, 40, 1, 1, 3), (64, 64, 80, 80, 1, 0, 1),
+    (64, 32, 37, 45, 2, 1, 2), (128, 64, 19, 23, 3, 1, 2), (32, 32, 17, 16, 4, 0, 3), (128, 128, 20, 20, 1, 1, 5),
+    (64, 64, 5, 3, 1, 1, 2),
+])
+def test_bottleneck_fused(gpu_device, cin, cmid, H, W, act, shortcut, batch):
+    """yamd_bottleneck (1x1 conv, 3x3 conv and the shortcut in one launch, the 1x1 output kept in LDS) against the two
+    yamd_conv2d_bias_act calls it replaces, the second one with 16-channel chunks (the fused kernel's order of
+    accumulation): bit-identical, also at image borders (the 3x3 conv pads the 1x1 conv's output, not its input), with
+    partial tiles, and when input and output are channel slices of wider buffers."""
+    from yolo_amd import lib as L
+    g = torch.Generator().manual_seed(cin * 1000 + cmid + H)
+    cout = cin
+    x = _bf16_round(torch.randn(batch, cin, H, W, generator=g))
+    w1 = torch.randn(cmid, cin, 1, 1, generator=g) / cin ** 0.5
+    b1 = torch.randn(cmid, generator=g) * 0.5
+    w2 = torch.randn(cout, cmid, 3, 3, generator=g) / (3 * cmid ** 0.5)
+    b2 = torch.randn(cout, generator=g) * 0.5
+    t = _run_conv(gpu_device, x, w1, b1, 1, 1, act)
+    want = _run_conv(gpu_device, t, w2, b2, 3, 1, act, res=x if shortcut else None, tiling=(1, 1, 16, 4, 1))
+
+    n = L.LIB.yamd_bottleneck_packed_elems(cin, cmid, cout)
+    assert n == cmid * cin + cout * cmid * 9
+    wp = torch.empty(n, dtype=torch.int16)
+    bp = torch.empty(cmid + cout, dtype=torch.float32)
+    L.check(L.LIB.yamd_bottleneck_pack_weights(cin, cmid, cout, w1.contiguous().data_ptr(), b1.data_ptr(), w2.contiguous().data_ptr(),
+                                               b2.data_ptr(), wp.data_ptr(), bp.data_ptr()))
+    wd, bd = wp.to(gpu_device), bp.to(gpu_device)
+    in_extra, out_extra = 8, 16
+    xin = torch.full((batch, H, W, cin + in_extra), 7.0, dtype=torch.bfloat16)
+    xin[..., in_extra:] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    xin = xin.to(gpu_device)
+    y = torch.full((batch, H, W, cout + out_extra), -3.0, dtype=torch.bfloat16, device=gpu_device)
+    L.check(L.LIB.yamd_bottleneck(cin, cmid, cout, act, xin.data_ptr() + in_extra * 2, xin.shape[-1], wd.data_ptr(), bd.data_ptr(),
+                                  shortcut, y.data_ptr() + out_extra * 2, y.shape[-1], batch, H, W, L.current_stream()), "bottleneck")
+    torch.cuda.synchronize()
+    yc = y.cpu().float()
+    assert torch.all(yc[..., :out_extra] == -3.0), "wrote outside its channel slice"
+    got = yc[..., out_extra:].permute(0, 3, 1, 2)
+    assert torch.equal(got, want), (float((got - want).abs().max()), int((got != want).sum()))
+
+    # refusals: a shape that is not built, and an output that overlaps the input
+    assert L.LIB.yamd_bottleneck_packed_elems(256, 256, 256) == 0
+    assert L.LIB.yamd_bottleneck(256, 256, 256, act, xin.data_ptr(), 256, wd.data_ptr(), bd.data_ptr(), 0, y.data_ptr(), 256,
+                                 1, 4, 4, L.current_stream()) != 0
+    assert L.LIB.yamd_bottleneck(cin, cmid, cout, act, xin.data_ptr() + in_extra * 2, xin.shape[-1], wd.data_ptr(), bd.data_ptr(),
+                                 0, xin.data_ptr() + in_extra * 2, xin.shape[-1], batch, H, W, L.current_stream()) != 0

@@ -29,6 +29,7 @@ SOURCES = [
     ("yamd_preprocess.hip", ["-ffp-contract=off"]),
     ("yamd_metric.hip", ["-ffp-contract=off"]),
     ("yamd_stem.hip", []),
+    ("yamd_bneck.hip", []),
     ("yamd_microbench.hip", []),
     ("yamd_plan.hip", []),
 ]

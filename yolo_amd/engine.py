@@ -33,7 +33,8 @@ class View(NamedTuple):
 # switch one off before building a model).  None of them changes a result beyond the bf16 rounding both forms share.
 FUSE = {"stem": True,          # first conv straight from the fp32 image (yamd_stem_conv)
         "stem_conv2": True,    # stride-2 stem + the 3x3 stride-2 conv after it as one launch (yamd_stem_conv2)
-        "upsample_cat": True}  # 1x1 convs read torch.cat((up(a), b), 1) from a and b themselves (yamd_conv2d_bias_act_cat2)
+        "upsample_cat": True,  # 1x1 convs read torch.cat((up(a), b), 1) from a and b themselves (yamd_conv2d_bias_act_cat2)
+        "bottleneck": True}    # 1x1 conv + 3x3 conv (+ shortcut) of a narrow residual unit as one launch (yamd_bottleneck)
 
 _PACK_GENERATION = [0]      # bumped whenever a layer's packed weights or descriptor change: compiled C plans are stale then
 
@@ -170,6 +171,41 @@ class StemConv2Layer:
 
     def to(self, device) -> None:
         self.stem.to(device)
+        if self.w_dev is None or self.w_dev.device != torch.device(device):
+            self.w_dev = self.w_host.to(device)
+            self.b_dev = self.b_host.to(device)
+
+
+class BottleneckLayer:
+    """A 1x1 conv and the 3x3 conv that follows it (plus the unit's shortcut) run as one launch (``yamd_bottleneck``):
+    the 1x1 conv's output is never written to memory."""
+
+    # (cin = cout, cmid) the plan fuses.  The library also builds (128, 128) and (128, 64); at those widths the unit is
+    # bound by arithmetic, not memory, and the two tuned launches are faster (207 against 243 us at 40 x 40, batch 256).
+    SHAPES = ((32, 32), (64, 64), (64, 32))
+
+    def __init__(self, first: ConvLayer, second: ConvLayer):
+        cmid, cin = first._w.shape[:2]
+        cout = second._w.shape[0]
+        self.name = f"{first.name}+{second.name}"
+        self.first, self.second = first, second
+        self.cin, self.cmid, self.cout, self.act = cin, cmid, cout, first._args[4]
+        self.macs_per_pixel = first.macs_per_pixel + second.macs_per_pixel
+        n = LIB.yamd_bottleneck_packed_elems(cin, cmid, cout)
+        if n <= 0:
+            raise _lib.YamdError(f"bottleneck[{self.name}]: {cin} > {cmid} > {cout} channels not supported")
+        self.w_host = torch.empty(n, dtype=torch.int16)
+        self.b_host = torch.empty(cmid + cout, dtype=torch.float32)
+        zeros = lambda k: torch.zeros(k, dtype=torch.float32)
+        b1 = first._b if first._b is not None else zeros(cmid)
+        b2 = second._b if second._b is not None else zeros(cout)
+        _lib.check(LIB.yamd_bottleneck_pack_weights(cin, cmid, cout, first._w.data_ptr(), b1.data_ptr(), second._w.data_ptr(),
+                                                    b2.data_ptr(), self.w_host.data_ptr(), self.b_host.data_ptr()),
+                   f"bottleneck_pack_weights[{self.name}]")
+        self.w_dev: Optional[torch.Tensor] = None
+        self.b_dev: Optional[torch.Tensor] = None
+
+    def to(self, device) -> None:
         if self.w_dev is None or self.w_dev.device != torch.device(device):
             self.w_dev = self.w_host.to(device)
             self.b_dev = self.b_host.to(device)
@@ -464,8 +500,8 @@ class Program:
         bufs = self._buffers_for(batch, device)
         buf, coff = self.resolve(v)
         if buf in self.fused_away:
-            raise _lib.YamdError(f"activation '{buf}' is not materialised: its layer runs fused with the next one "
-                                 "(set yolo_amd.engine.FUSE['stem_conv2'] = False before building the model to inspect it)")
+            raise _lib.YamdError(f"activation '{buf}' is not materialised: its layer runs fused with the next one (set "
+                                 "yolo_amd.engine.FUSE['stem_conv2'] / ['bottleneck'] = False before building the model to inspect it)")
         if any(b == buf and c0 < coff + v.c and c1 > coff for b, c0, c1 in self.unwritten):
             raise _lib.YamdError(f"activation '{buf}'[{coff}:{coff + v.c}] is not materialised: its readers take the upsampled "
                                  "tensor from the low-resolution one (set yolo_amd.engine.FUSE['upsample_cat'] = False before "
@@ -473,7 +509,7 @@ class Program:
         return bufs[buf][..., coff:coff + v.c].permute(0, 3, 1, 2).float().contiguous()
 
     def n_conv_launches(self) -> int:
-        return sum(1 for op in self.ops if op[0] in ("conv", "conv_cat2", "stem", "stem2"))
+        return sum(1 for op in self.ops if op[0] in ("conv", "conv_cat2", "stem", "stem2", "bneck"))
 
     def conv_macs_per_image(self) -> int:
         total = 0
@@ -482,6 +518,8 @@ class Program:
                 total += op[1].macs_per_pixel * op[3].h * op[3].w
             elif op[0] == "conv_cat2":
                 total += op[1].macs_per_pixel * op[6].h * op[6].w
+            elif op[0] == "bneck":      # the MACs of the two layers, not of the fused kernel (which recomputes the halo of the first)
+                total += op[1].macs_per_pixel * op[3].h * op[3].w
             elif op[0] == "stem":
                 total += op[1].macs_per_pixel * op[2].h * op[2].w
             elif op[0] == "stem2":      # the MACs of the two layers, not of the fused kernel (which recomputes tile overlaps)
@@ -513,6 +551,10 @@ class Program:
             cout = out.c + (out2.c if out2 is not None else 0)
             byts = batch * (xa.h * xa.w * xa.c + xb.h * xb.w * xb.c) * 2 + px * cout * (4 if layer.desc.out_f32 else 2) + layer.macs_per_pixel * 2
             return 2.0 * layer.macs_per_pixel * px, float(byts)
+        if kind == "bneck":
+            _, layer, x, out, _sc = op
+            px = batch * out.h * out.w
+            return 2.0 * layer.macs_per_pixel * px, float(px * (x.c + out.c) * 2 + layer.macs_per_pixel * 2)
         if kind == "stem":
             _, layer, out = op
             px = batch * out.h * out.w
@@ -547,6 +589,8 @@ class Program:
             return [v for v in (op[2], op[4]) if v is not None]
         if kind == "conv_cat2":
             return [op[2], op[4]]
+        if kind == "bneck":
+            return [op[2]]
         if kind in ("up2", "copy", "d2s", "mp2", "mp5"):
             return [op[1]]
         return []
@@ -596,11 +640,57 @@ class Program:
             removed += 1
         return removed
 
+    def fuse_bottlenecks(self) -> int:
+        """Replaces every 1x1 conv directly followed by the 3x3 stride-1 conv that is its only reader (same activation,
+        shortcut from the 1x1 conv's input or none) by one ``bneck`` op when the library builds the fused kernel for
+        those widths; the tensor between them is dropped.  Returns the number of pairs fused.  Runs once, before the
+        first buffers are allocated."""
+        def rng(v: View):
+            buf, coff = self.resolve(v)
+            return buf, coff, coff + v.c
+
+        def overlaps(a, b):
+            return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
+
+        fused, j = 0, 0
+        while j + 1 < len(self.ops):
+            a, b = self.ops[j], self.ops[j + 1]
+            j += 1
+            if a[0] != "conv" or b[0] != "conv":
+                continue
+            _, l1, x, t, res1, t2 = a
+            _, l2, t_in, y, res2, y2 = b
+            k1, s1, cin1, cmid, act1, f1 = l1._args
+            k2, s2, _cin2, cout, act2, f2 = l2._args
+            if not (k1 == 1 and k2 == 3 and s1 == 1 and s2 == 1 and act1 == act2 and not f1 and not f2 and res1 is None
+                    and t2 is None and y2 is None and rng(t_in) == rng(t) and l1.cin_real == x.c and l2.cin_real == t.c
+                    and x.c == cout and (x.c, cmid) in BottleneckLayer.SHAPES and l2.residual_scale == 1.0
+                    and (res2 is None or rng(res2) == rng(x))):
+                continue
+            tr = rng(t)
+            if t.buf in self.alias or self.buffers[t.buf][2] != t.c or any(overlaps(rng(v), tr) for v in self.outputs.values()):
+                continue
+            if any(overlaps(rng(v), tr) for k, op in enumerate(self.ops) if k != j for v in self._inputs_of(op)):
+                continue      # (k == j is the 3x3 conv itself; ops[j - 1] has no input in t)
+            if overlaps(rng(x), rng(y)):
+                continue
+            layer = BottleneckLayer(l1, l2)
+            self.ops[j - 1:j + 1] = [("bneck", layer, x, y, int(res2 is not None))]
+            self.convs.remove(l1)
+            self.convs.remove(l2)
+            self.stems.append(layer)
+            del self.buffers[t.buf]
+            self.fused_away.add(t.buf)
+            fused += 1
+        return fused
+
     def _buffers_for(self, batch: int, device) -> Dict[str, torch.Tensor]:
         if not self._finalized:
             self._finalized = True
             if FUSE["upsample_cat"]:
                 self.fuse_upsample_cat()
+            if FUSE["bottleneck"]:
+                self.fuse_bottlenecks()
         key = (batch, str(device))
         if key not in self._alloc:
             self._alloc.clear()   # one live batch size at a time: the arena is large
@@ -663,6 +753,13 @@ class Program:
                 fill(_lib.OP_CONV_CAT2, (xacs, xbcs, ycs, out.h, out.w, y2cs, out.c if out2 is not None else 0, xa.c, a_half | (b_half << 1)),
                      {0: xap, 1: layer.w_dev.data_ptr(), 2: layer.b_dev.data_ptr(), 3: xbp, 4: yp, 5: y2p})
                 names.append(f"conv[{layer.name}]")
+            elif kind == "bneck":
+                _, layer, x, out, shortcut = op
+                xp, xcs = P(bufs, x)
+                yp, ycs = P(bufs, out)
+                fill(_lib.OP_BOTTLENECK, (xcs, layer.cin, ycs, out.h, out.w, layer.cmid, layer.cout, layer.act, shortcut),
+                     {0: xp, 1: layer.w_dev.data_ptr(), 2: layer.b_dev.data_ptr(), 4: yp})
+                names.append(f"bottleneck[{layer.name}]")
             elif kind == "stem":
                 _, layer, out = op
                 yp, ycs = P(bufs, out)
@@ -734,7 +831,7 @@ class Program:
         for op in self.ops:
             kind = op[0]
             if conv_spans is not None:
-                is_conv = kind in ("conv", "conv_cat2", "stem", "stem2")
+                is_conv = kind in ("conv", "conv_cat2", "stem", "stem2", "bneck")
                 if is_conv and span_open is None:
                     span_open = torch.cuda.Event(enable_timing=True)
                     span_open.record()
@@ -769,6 +866,12 @@ class Program:
                 _lib.check(LIB.yamd_conv2d_bias_act_cat2(ctypes.byref(layer.desc), xap, xacs, xa.c, a_half, xbp, xbcs, b_half,
                                                          layer.w_dev.data_ptr(), layer.b_dev.data_ptr(), yp, ycs, y2p, y2cs,
                                                          out.c if out2 is not None else 0, B, out.h, out.w, st), f"conv[{layer.name}]")
+            elif kind == "bneck":
+                _, layer, x, out, shortcut = op
+                xp, xcs = P(bufs, x)
+                yp, ycs = P(bufs, out)
+                _lib.check(LIB.yamd_bottleneck(layer.cin, layer.cmid, layer.cout, layer.act, xp, xcs, layer.w_dev.data_ptr(),
+                                               layer.b_dev.data_ptr(), shortcut, yp, ycs, B, out.h, out.w, st), f"bottleneck[{layer.name}]")
             elif kind == "stem":
                 _, layer, out = op
                 yp, ycs = P(bufs, out)
@@ -820,7 +923,7 @@ class Program:
             if timings is not None:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
-                if kind in ("stem", "stem2", "conv_cat2"):          # reported with the convs
+                if kind in ("stem", "stem2", "conv_cat2", "bneck"):          # reported with the convs
                     timings.append(("conv", op[1].name, ev0, ev1) + self.op_cost(op, B))
                 else:
                     timings.append((kind, op[1].name if kind == "conv" else kind, ev0, ev1) + self.op_cost(op, B))

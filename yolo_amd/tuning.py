@@ -69,6 +69,7 @@ def main() -> None:
     ap.add_argument("--reps", type=int, default=10, help="timed launches per candidate")
     ap.add_argument("--in-situ", action="store_true", help="time candidates inside whole-program runs (realistic cache state)")
     ap.add_argument("--missing-only", action="store_true", help="measure only the layer shapes the table does not hold yet")
+    ap.add_argument("--only", default="", help="measure only the layer shapes whose key starts with this (e.g. k3s2)")
     args = ap.parse_args()
     global enabled
     if args.missing_only:
@@ -84,7 +85,14 @@ def main() -> None:
     if args.in_situ:
         best = prog.autotune_in_situ(imgs, reps=args.reps, log=print)
     else:
-        best = prog.autotune(args.batch, dev, reps=args.reps, log=print, skip=set(table()) if args.missing_only else ())
+        skip = set(table()) if args.missing_only else set()
+        if args.only:
+            for op in prog.ops:
+                if op[0] == "conv" and not op[1].desc.out_f32:
+                    k_ = key(op[1]._args[0], op[1]._args[1], op[2].c, op[3].c + (op[5].c if op[5] is not None else 0), op[3].h, op[3].w)
+                    if not k_.startswith(args.only):
+                        skip.add(k_)
+        best = prog.autotune(args.batch, dev, reps=args.reps, log=print, skip=skip)
     save(best, args.out)
     print(f"{len(best)} layer shapes -> {args.out}")
 
