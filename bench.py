@@ -512,12 +512,12 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(conv_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(conv_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_src,
-                         "kernel": "conv_igemm_kernel + stem_conv2_kernel / stem_conv_kernel (all %d fused conv launches of one step)" % n_conv,
+                         "kernel": "conv_igemm_kernel + bneck_kernel + stem_conv2_kernel / stem_conv_kernel (all %d fused conv launches of one step)" % n_conv,
                          "how": "achieved = conv FLOPs of one step (2 x MACs of every conv launch) / conv time of one step; "
                                 "conv time = HIP events on the launch stream around every run of consecutive conv launches "
                                 "inside the timed region, summed over the %d steps / %d (in the pipeline: the previous step's "
                                 "D2H copy runs underneath).  The rocprofv3 kernel trace of this command gives the same sum per kernel "
-                                "(conv_igemm + stem rows of profiles/*_kernel_stats.csv / program runs) except for the first kernel of "
+                                "(conv_igemm + bneck + stem rows of profiles/*_kernel_stats.csv / program runs) except for the first kernel of "
                                 "a step, the fused stem, which runs longer under the profiler: the previous step's row copy is a "
                                 "blit kernel beside it there" % (args.steps, args.steps),
                          "flops_per_launch": prof["conv_flops"] / n_conv,
