@@ -197,6 +197,47 @@ def test_upsample_cat_rewrite_of_the_recorded_ops():
     assert prog.fuse_upsample_cat() == 0 and any(op[0] == "up2" for op in prog.ops)
 
 
+def test_bottleneck_rewrite_of_the_recorded_ops():
+    """Program.fuse_bottlenecks on the host: a 1x1 conv followed by the 3x3 conv that is its only reader becomes one
+    ``bneck`` op for the widths the plan selects; conv launches drop by one per pair, MACs and outputs do not change, the
+    tensor between the two convs is gone; pairs that do not fit (another reader of the 1x1 output, a shortcut from
+    somewhere else, different activations, 128 channels) stay as they are."""
+    import torch
+    from yolo_amd import engine, lib as L, models
+    for name, n_fused in (("v5s", 5), ("v3", 1), ("v4", 3), ("v8s", 0), ("v5m", 0)):
+        p, m = models.create(name, img_size=128)
+        prog = m.program()
+        convs, macs, nbuf = prog.n_conv_launches(), prog.conv_macs_per_image(), len(prog.buffers)
+        assert prog.fuse_bottlenecks() == n_fused
+        units = [op for op in prog.ops if op[0] == "bneck"]
+        assert len(units) == n_fused and prog.n_conv_launches() == convs - n_fused and prog.conv_macs_per_image() == macs
+        assert len(prog.buffers) == nbuf - n_fused
+        for _, layer, x, y, shortcut in units:
+            assert (layer.cin, layer.cmid) in engine.BottleneckLayer.SHAPES and layer.cout == layer.cin == x.c == y.c
+            assert (x.h, x.w) == (y.h, y.w) and prog.resolve(x) != prog.resolve(y)
+            assert layer.first not in prog.convs and layer.second not in prog.convs and layer in prog.stems
+        assert prog.fuse_bottlenecks() == 0           # nothing left to do
+
+    def pair(prog, c, act2=L.ACT_SILU, extra_reader=False, res="x", cmid=None):
+        cmid = cmid or c
+        x = prog.conv("x", prog.image16(), torch.zeros(c, 3, 3, 3), None, 2, L.ACT_SILU)
+        other = prog.conv("other", x, torch.zeros(c, c, 1, 1), None, 1, L.ACT_SILU)
+        t = prog.conv("t", x, torch.zeros(cmid, c, 1, 1), None, 1, L.ACT_SILU)
+        y = prog.conv("y", t, torch.zeros(c, cmid, 3, 3), None, 1, act2, residual={"x": x, "other": other, None: None}[res])
+        if extra_reader:
+            prog.conv("z", t, torch.zeros(c, cmid, 1, 1), None, 1, L.ACT_SILU)
+        return y
+
+    for kw, want in (({}, 1), ({"res": None}, 1), ({"cmid": 32}, 1), ({"act2": L.ACT_RELU}, 0), ({"extra_reader": True}, 0),
+                     ({"res": "other"}, 0)):
+        prog = engine.Program(64, 64)
+        pair(prog, 64, **kw)
+        assert prog.fuse_bottlenecks() == want, kw
+    prog = engine.Program(64, 64)
+    pair(prog, 128)
+    assert prog.fuse_bottlenecks() == 0                # built in the library, not selected by the plan
+
+
 def test_plan_follows_weights_loaded_through_a_submodule():
     """The compiled plan is keyed on the parameters themselves: loading weights into a submodule (the way the reference
     loads a pretrained backbone), changing a tensor in place or changing the Param fields the plan reads all give a
