@@ -44,6 +44,8 @@ struct NmsParams {
     float4 *sbox, *mbox;
     u32 *mrank, *posr;
     int sort_cap;
+    int big_occ8;                // buckets too large for the LDS sort also run in the two-per-compute-unit instantiation
+    int cache_off, cache_groups; // LDS box cache of the sweep: byte offset behind the sweep state, capacity in groups of 64 boxes
     int frows;                   // rows per workgroup of the filter (256, fewer when a row is very wide)
     u32 *img_count, *cls_count, *cls_off, *kcnt;
     float *out_rows;
@@ -83,7 +85,7 @@ __device__ __forceinline__ void row_best(const float *cls, int nc, float &best, 
 }
 
 constexpr int FROWS = 256;
-constexpr int REGQ = 8;   // groups per wave whose boxes are kept in registers during the NMS sweep
+constexpr int REGQ = 2;   // groups per wave whose boxes are kept in registers during the NMS sweep
 
 __global__ __launch_bounds__(256) void nms_filter_kernel(NmsParams p)
 {
@@ -334,7 +336,8 @@ __device__ __forceinline__ float rl(float v, int lane) { return __uint_as_float(
 //       A(t+1) in the same interval every wave computes 4 columns of the next tile's suppression matrix.
 //     The bounding-box test only skips pairs whose intersection is exactly empty, so the kept set is
 //     the one the plain greedy loop produces.
-__global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
+template <int MIN_WAVES>
+__global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(NmsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_seg[];
     // image index fastest: workgroups are dealt round-robin over the 8 XCDs in linear block order, and the
@@ -360,6 +363,11 @@ __global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
     u32 npad = 8;
     while (npad < n) npad <<= 1;
     const bool in_lds = npad <= (u32)p.sort_cap;
+    // Two instantiations share the grid: the one limited to 64 registers runs two workgroups per compute unit (one
+    // fills the other's serial phases) and takes the buckets whose sort fits LDS; a bucket beyond that is sorted in
+    // global memory and, unless there are more such buckets than compute units (p.big_occ8), is alone on its
+    // compute unit for most of its time: it takes the instantiation without the register limit.
+    if ((in_lds || p.big_occ8) != (MIN_WAVES == 8)) return;
     u64 *S = in_lds ? (u64 *)smem_seg : skey;
     for (u32 i = tid; i < n; i += SEG_THREADS) S[in_lds ? lds_slot(i) : i] = keys[i];
     __syncthreads();
@@ -400,37 +408,41 @@ __global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
     if (in_lds) {
         // at most RPT ranks per thread (r = tid + 1024 q): keys, boxes, cells and tickets stay in registers, and the
         // scattered row reads of a thread are all in flight together
-        constexpr int RPT = 8192 / SEG_THREADS;
-        u64 kq[RPT];
-        float raw[RPT][4];
-        float4 ob[RPT];
+        constexpr int RPT = 8192 / SEG_THREADS, RH = 2;
         u32 cq[RPT], tq[RPT];
+        // in two halves, so that the registers of the rows in flight (4 ranks x (key + 4 floats)) stay few enough for
+        // two workgroups per compute unit
 #pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const u32 r = tid + SEG_THREADS * q;
-            kq[q] = r < n ? S[lds_slot(r)] : 0ull;
-        }
+        for (int h = 0; h < RPT / RH; ++h) {
+            u64 kq[RH];
+            float raw[RH][4];
 #pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const u32 r = tid + SEG_THREADS * q;
-            if (r < n) {
-                const float *row = p.pred + (b * p.A + (0xFFFFFFFFu - (u32)kq[q])) * (long long)p.C;
-                raw[q][0] = row[0]; raw[q][1] = row[1]; raw[q][2] = row[2]; raw[q][3] = row[3];
-            } else {
-                raw[q][0] = raw[q][1] = raw[q][2] = raw[q][3] = 0.f;
+            for (int q = 0; q < RH; ++q) {
+                const u32 r = tid + SEG_THREADS * (h * RH + q);
+                kq[q] = r < n ? S[lds_slot(r)] : 0ull;
             }
-        }
 #pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const u32 r = tid + SEG_THREADS * q;
-            float x1, y1, x2, y2;
-            row_box(raw[q], p.in_cxcywh, p.hi, x1, y1, x2, y2);
-            ob[q] = make_float4(x1 + coff, y1 + coff, x2 + coff, y2 + coff);
-            cq[q] = cell_of(x1, y1, x2, y2);
-            if (r < n) {
-                skey[r] = kq[q];
-                sbox[r] = ob[q];
-                if (!grouped) { mrank[r] = r; posr[r] = r; mbox[r] = ob[q]; }
+            for (int q = 0; q < RH; ++q) {
+                const u32 r = tid + SEG_THREADS * (h * RH + q);
+                if (r < n) {
+                    const float *row = p.pred + (b * p.A + (0xFFFFFFFFu - (u32)kq[q])) * (long long)p.C;
+                    raw[q][0] = row[0]; raw[q][1] = row[1]; raw[q][2] = row[2]; raw[q][3] = row[3];
+                } else {
+                    raw[q][0] = raw[q][1] = raw[q][2] = raw[q][3] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < RH; ++q) {
+                const u32 r = tid + SEG_THREADS * (h * RH + q);
+                float x1, y1, x2, y2;
+                row_box(raw[q], p.in_cxcywh, p.hi, x1, y1, x2, y2);
+                const float4 ob = make_float4(x1 + coff, y1 + coff, x2 + coff, y2 + coff);
+                cq[h * RH + q] = cell_of(x1, y1, x2, y2);
+                if (r < n) {
+                    skey[r] = kq[q];
+                    sbox[r] = ob;
+                    if (!grouped) { mrank[r] = r; posr[r] = r; mbox[r] = ob; }
+                }
             }
         }
         __syncthreads();                                // the sorted keys in LDS are dead from here
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
                     const u32 sp = hist[cq[q]] + tq[q];
                     mrank[sp] = r;
                     posr[r] = sp;
-                    mbox[sp] = ob[q];
+                    mbox[sp] = sbox[r];                 // this thread's own store above
                 }
             }
         }
@@ -514,16 +526,22 @@ __global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
         }
     }
 
-    // Boxes of this wave's groups (g = wave + 16q) stay in registers for the whole sweep when the bucket
-    // has at most 64*16*REGQ boxes; phase C then touches no global memory at all.
-    const bool use_regs = ng <= (u32)(SEG_WAVES * REGQ);
+    // Boxes of this wave's first REGQ groups (g = wave + 16q) stay in registers for the whole sweep, the next
+    // p.cache_groups groups of the bucket in LDS: phase C touches global memory only for what lies beyond both.
     float4 rb[REGQ];
-    if (use_regs) {
 #pragma unroll
-        for (int q = 0; q < REGQ; ++q) {
-            const u32 s = (wave + SEG_WAVES * q) * 64 + lane;
-            rb[q] = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int q = 0; q < REGQ; ++q) {
+        const u32 s = (wave + SEG_WAVES * q) * 64 + lane;
+        rb[q] = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // the next groups wait in LDS behind the sweep state (the sort array is dead): a lane reads back only what it
+    // wrote itself, so no barrier orders these stores
+    constexpr u32 G0 = SEG_WAVES * REGQ;
+    float4 *lbox = (float4 *)(smem_seg + p.cache_off);
+    const u32 ncache = ng > G0 ? min((u32)p.cache_groups, ng - G0) : 0u;
+    for (u32 g = G0 + wave; g < G0 + ncache; g += SEG_WAVES) {
+        const u32 s = g * 64 + lane;
+        lbox[(g - G0) * 64 + lane] = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     // columns [4*wave, 4*wave+4) of tile `t`'s suppression matrix: bit j of column i = box i removes box j > i
@@ -604,59 +622,42 @@ __global__ __launch_bounds__(SEG_THREADS) void nms_segment_kernel(NmsParams p)
             const u32 first_later = (t + 1) * 64;
             float4 kx = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((u32)lane < nk) kx = kb[lane];
-            if (use_regs) {
+            // kept boxes of this tile against one group's boxes (fetched by `boxes` once the group is known to need them)
+            auto apply = [&](const u32 g, auto boxes) __attribute__((always_inline)) {
+                const float4 bb = gbb[g];
+                const bool ov = (u32)lane < nk && kx.z > bb.x && kx.x < bb.z && kx.w > bb.y && kx.y < bb.w;
+                u64 rel = __ballot(ov);
+                if (rel == 0ull) return;
+                const bool todo = g * 64 + lane < n && !((rem[g] >> lane) & 1ull);
+                if (__ballot(todo) == 0ull) return;
+                const float4 jx = boxes();
+                const float ja = (jx.z - jx.x) * (jx.w - jx.y);
+                bool sup = false;
+                while (rel) {
+                    const int k = __ffsll((long long)rel) - 1;
+                    rel &= rel - 1ull;
+                    const float4 qb = kb[k];
+                    // a kept box that touches the group's bounding box but none of its boxes: no lane has an
+                    // intersection, and a zero intersection never suppresses (the threshold is >= 0): skip the division
+                    const float inter = iou_inter(qb.x, qb.y, qb.z, qb.w, jx.x, jx.y, jx.z, jx.w);
+                    if (__ballot(inter > 0.0f) == 0ull) continue;
+                    sup = sup || iou_ratio_gt(inter, ka[k], ja, p.iou_thr);
+                }
+                const u64 sm = __ballot(sup && todo);
+                if (lane == 0 && sm) atomicOr(&rem[g], sm);
+            };
 #pragma unroll
-                for (int q = 0; q < REGQ; ++q) {
-                    const u32 g = wave + SEG_WAVES * q;
-                    if (g >= ng || gmax[g] < first_later) continue;
-                    const float4 bb = gbb[g];
-                    const bool ov = (u32)lane < nk && kx.z > bb.x && kx.x < bb.z && kx.w > bb.y && kx.y < bb.w;
-                    u64 rel = __ballot(ov);
-                    if (rel == 0ull) continue;
-                    const bool todo = g * 64 + lane < n && !((rem[g] >> lane) & 1ull);
-                    if (__ballot(todo) == 0ull) continue;
-                    const float4 jx = rb[q];
-                    const float ja = (jx.z - jx.x) * (jx.w - jx.y);
-                    bool sup = false;
-                    while (rel) {
-                        const int k = __ffsll((long long)rel) - 1;
-                        rel &= rel - 1ull;
-                        const float4 qb = kb[k];
-                        // a kept box that touches the group's bounding box but none of its boxes: no lane has an
-                        // intersection, and a zero intersection never suppresses (the threshold is >= 0): skip the division
-                        const float inter = iou_inter(qb.x, qb.y, qb.z, qb.w, jx.x, jx.y, jx.z, jx.w);
-                        if (__ballot(inter > 0.0f) == 0ull) continue;
-                        sup = sup || iou_ratio_gt(inter, ka[k], ja, p.iou_thr);
-                    }
-                    const u64 sm = __ballot(sup && todo);
-                    if (lane == 0 && sm) atomicOr(&rem[g], sm);
-                }
-            } else {
-                for (u32 g = wave; g < ng; g += SEG_WAVES) {
-                    if (gmax[g] < first_later) continue;
-                    const float4 bb = gbb[g];
-                    const bool ov = (u32)lane < nk && kx.z > bb.x && kx.x < bb.z && kx.w > bb.y && kx.y < bb.w;
-                    u64 rel = __ballot(ov);
-                    if (rel == 0ull) continue;
+            for (int q = 0; q < REGQ; ++q) {
+                const u32 g = wave + SEG_WAVES * q;
+                if (g < ng && gmax[g] >= first_later) apply(g, [&]() __attribute__((always_inline)) { return rb[q]; });
+            }
+            for (u32 g = G0 + wave; g < ng; g += SEG_WAVES) {
+                if (gmax[g] < first_later) continue;
+                apply(g, [&]() __attribute__((always_inline)) {
                     const u32 s = g * 64 + lane;
-                    const bool todo = s < n && !((rem[g] >> lane) & 1ull);
-                    if (__ballot(todo) == 0ull) continue;
-                    const float4 jx = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-                    const float ja = (jx.z - jx.x) * (jx.w - jx.y);
-                    bool sup = false;
-                    while (rel) {
-                        const int k = __ffsll((long long)rel) - 1;
-                        rel &= rel - 1ull;
-                        const float4 qb = kb[k];
-                        // a kept box that touches the group's bounding box but none of its boxes: no lane has an
-                        // intersection, and a zero intersection never suppresses (the threshold is >= 0): skip the division
-                        const float inter = iou_inter(qb.x, qb.y, qb.z, qb.w, jx.x, jx.y, jx.z, jx.w);
-                        if (__ballot(inter > 0.0f) == 0ull) continue;
-                        sup = sup || iou_ratio_gt(inter, ka[k], ja, p.iou_thr);
-                    }
-                    const u64 sm = __ballot(sup && todo);
-                    if (lane == 0 && sm) atomicOr(&rem[g], sm);
-                }
+                    if (g - G0 < ncache) return lbox[(g - G0) * 64 + lane];
+                    return s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+                });
             }
         }
         if (have_next) {
@@ -961,7 +962,8 @@ int nms_init_current_device(int device)
 {
     (void)device;
     int rc = KernelAttr<&nms_filter_kernel, 160 * 1024>::ensure();
-    if (rc == YAMD_OK) rc = KernelAttr<&nms_segment_kernel, 160 * 1024>::ensure();
+    if (rc == YAMD_OK) rc = KernelAttr<&nms_segment_kernel<8>, 160 * 1024>::ensure();
+        if (rc == YAMD_OK) rc = KernelAttr<&nms_segment_kernel<4>, 160 * 1024>::ensure();
     if (rc == YAMD_OK) rc = KernelAttr<&nms_gather_sort_kernel, 150 * 1024>::ensure();
     if (rc != YAMD_OK) return rc;
     void *ptr = nullptr;
@@ -1038,12 +1040,36 @@ int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, 
     const size_t group_lds = (size_t)(CELLS + SEG_WAVES) * 4;
     if (slds < group_lds) slds = group_lds;
     YAMD_REQUIRE(slds <= 160 * 1024, "A=%d needs %zu bytes of LDS for the sweep", a, slds);
+    // the sweep's box cache fills what two workgroups per compute unit leave behind the sweep state
+    const size_t cache_off = (sweep_lds + 15) & ~(size_t)15;
+    const size_t beyond_regs = ngmax > (size_t)SEG_WAVES * REGQ ? ngmax - (size_t)SEG_WAVES * REGQ : 0;
+    size_t cache_groups = 0;
+    if (cache_off + 1024 <= 80 * 1024) {
+        cache_groups = (80 * 1024 - cache_off) / 1024;
+        if (cache_groups > beyond_regs) cache_groups = beyond_regs;
+        if (slds < cache_off + cache_groups * 1024) slds = cache_off + cache_groups * 1024;
+    }
     char *ws = (char *)workspace;
     NmsParams p;
     p.pred = pred;
     p.B = batch; p.A = a; p.C = c; p.in_cxcywh = in_cxcywh ? 1 : 0; p.n_extra = n_extra; p.nc = nc;
     p.W = 7 + n_extra;
     p.sort_cap = sort_cap;
+    {
+        // such buckets only come one or a few per image (most candidates of an image in one class): with more images
+        // than compute units they queue up, and two per compute unit beat one faster workgroup
+        static std::atomic<int> cus[64];
+        int dev = 0;
+        YAMD_HIP(hipGetDevice(&dev));
+        int ncu = dev >= 0 && dev < 64 ? cus[dev].load(std::memory_order_relaxed) : 0;
+        if (ncu == 0) {
+            YAMD_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+            if (dev >= 0 && dev < 64) cus[dev].store(ncu, std::memory_order_relaxed);
+        }
+        p.big_occ8 = batch > ncu ? 1 : 0;
+    }
+    p.cache_off = (int)cache_off;
+    p.cache_groups = (int)cache_groups;
     p.max_out = max_out;
     p.hi = img_size - 1.0f;
     p.conf_thr = conf_thr;
@@ -1072,7 +1098,8 @@ int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, 
 
     {
         int rc = KernelAttr<&nms_filter_kernel, 160 * 1024>::ensure();
-        if (rc == YAMD_OK) rc = KernelAttr<&nms_segment_kernel, 160 * 1024>::ensure();
+        if (rc == YAMD_OK) rc = KernelAttr<&nms_segment_kernel<8>, 160 * 1024>::ensure();
+        if (rc == YAMD_OK) rc = KernelAttr<&nms_segment_kernel<4>, 160 * 1024>::ensure();
         if (rc == YAMD_OK) rc = KernelAttr<&nms_gather_sort_kernel, 150 * 1024>::ensure();
         if (rc != YAMD_OK) return rc;
     }
@@ -1090,8 +1117,12 @@ int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, 
     YAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_bucket_kernel, dim3(achunks, batch), dim3(256), 0, st, p);
     YAMD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_segment_kernel, dim3(batch, nc), dim3(SEG_THREADS), slds, st, p);
+    hipLaunchKernelGGL(nms_segment_kernel<8>, dim3(batch, nc), dim3(SEG_THREADS), slds, st, p);
     YAMD_LAUNCH_CHECK();
+    if (a > sort_cap && !p.big_occ8) {      // buckets larger than the LDS sort can exist
+        hipLaunchKernelGGL(nms_segment_kernel<4>, dim3(batch, nc), dim3(SEG_THREADS), slds, st, p);
+        YAMD_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(nms_gather_sort_kernel, dim3(batch), dim3(GATHER_THREADS), (size_t)GSORT_CAP * sizeof(u64), st, p);
     YAMD_LAUNCH_CHECK();
     {
