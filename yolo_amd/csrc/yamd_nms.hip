@@ -536,12 +536,22 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
     }
     // the next groups wait in LDS behind the sweep state (the sort array is dead): a lane reads back only what it
     // wrote itself, so no barrier orders these stores
+    // The last `ng % 16` groups of a bucket do not fill a round of one group per wave: each of them is shared by
+    // 16 / (ng % 16) waves that split the kept boxes between them (a bucket of 20 groups otherwise costs two rounds
+    // of which the second keeps 4 of the 16 waves busy).  Those waves are not the groups' owners, so the boxes come
+    // from the LDS cache, which therefore starts at group `cbase` = 16 (0 for buckets of fewer than 16 groups); the
+    // barrier before the first tile orders its stores.
     constexpr u32 G0 = SEG_WAVES * REGQ;
+    const u32 full = ng & ~(u32)(SEG_WAVES - 1);
+    const u32 tail = ng - full;
+    const u32 tparts = tail ? (u32)SEG_WAVES / tail : 1u;
+    const u32 tgroup = full + (u32)wave / tparts, tpart = (u32)wave % tparts;
+    const u32 cbase = min(full, (u32)SEG_WAVES);
     float4 *lbox = (float4 *)(smem_seg + p.cache_off);
-    const u32 ncache = ng > G0 ? min((u32)p.cache_groups, ng - G0) : 0u;
-    for (u32 g = G0 + wave; g < G0 + ncache; g += SEG_WAVES) {
+    const u32 ncache = min((u32)p.cache_groups, ng - cbase);
+    for (u32 g = cbase + wave; g < cbase + ncache; g += SEG_WAVES) {
         const u32 s = g * 64 + lane;
-        lbox[(g - G0) * 64 + lane] = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        lbox[(g - cbase) * 64 + lane] = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     // columns [4*wave, 4*wave+4) of tile `t`'s suppression matrix: bit j of column i = box i removes box j > i
@@ -623,10 +633,22 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             float4 kx = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((u32)lane < nk) kx = kb[lane];
             // kept boxes of this tile against one group's boxes (fetched by `boxes` once the group is known to need them)
-            auto apply = [&](const u32 g, auto boxes) __attribute__((always_inline)) {
+            auto apply = [&](const u32 g, const u32 part, const u32 parts, auto boxes) __attribute__((always_inline)) {
                 const float4 bb = gbb[g];
                 const bool ov = (u32)lane < nk && kx.z > bb.x && kx.x < bb.z && kx.w > bb.y && kx.y < bb.w;
                 u64 rel = __ballot(ov);
+                if (parts > 1u) {
+                    // this wave's share of the relevant kept boxes: number part, part + parts, ... (picked here, on the
+                    // scalar unit, so that the loop over them below stays as it is)
+                    u64 r = rel, m = 0ull;
+                    u32 ord = 0u, mine = part;
+                    while (r) {
+                        const u64 low = r & (0ull - r);
+                        r ^= low;
+                        if (ord++ == mine) { m |= low; mine += parts; }
+                    }
+                    rel = m;
+                }
                 if (rel == 0ull) return;
                 const bool todo = g * 64 + lane < n && !((rem[g] >> lane) & 1ull);
                 if (__ballot(todo) == 0ull) return;
@@ -646,19 +668,20 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
                 const u64 sm = __ballot(sup && todo);
                 if (lane == 0 && sm) atomicOr(&rem[g], sm);
             };
+            auto cached = [&](const u32 g) __attribute__((always_inline)) {
+                const u32 s = g * 64 + lane;
+                if (g - cbase < ncache) return lbox[(g - cbase) * 64 + lane];
+                return s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+            };
 #pragma unroll
             for (int q = 0; q < REGQ; ++q) {
                 const u32 g = wave + SEG_WAVES * q;
-                if (g < ng && gmax[g] >= first_later) apply(g, [&]() __attribute__((always_inline)) { return rb[q]; });
+                if (g < full && gmax[g] >= first_later) apply(g, 0u, 1u, [&]() __attribute__((always_inline)) { return rb[q]; });
             }
-            for (u32 g = G0 + wave; g < ng; g += SEG_WAVES) {
-                if (gmax[g] < first_later) continue;
-                apply(g, [&]() __attribute__((always_inline)) {
-                    const u32 s = g * 64 + lane;
-                    if (g - G0 < ncache) return lbox[(g - G0) * 64 + lane];
-                    return s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-                });
-            }
+            for (u32 g = G0 + wave; g < full; g += SEG_WAVES)
+                if (gmax[g] >= first_later) apply(g, 0u, 1u, [&]() __attribute__((always_inline)) { return cached(g); });
+            if (tgroup < ng && gmax[tgroup] >= first_later)
+                apply(tgroup, tpart, tparts, [&]() __attribute__((always_inline)) { return cached(tgroup); });
         }
         if (have_next) {
             bx = nbx;
@@ -1042,7 +1065,7 @@ int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, 
     YAMD_REQUIRE(slds <= 160 * 1024, "A=%d needs %zu bytes of LDS for the sweep", a, slds);
     // the sweep's box cache fills what two workgroups per compute unit leave behind the sweep state
     const size_t cache_off = (sweep_lds + 15) & ~(size_t)15;
-    const size_t beyond_regs = ngmax > (size_t)SEG_WAVES * REGQ ? ngmax - (size_t)SEG_WAVES * REGQ : 0;
+    const size_t beyond_regs = ngmax > (size_t)SEG_WAVES ? ngmax - (size_t)SEG_WAVES : ngmax;      // see cbase in the kernel
     size_t cache_groups = 0;
     if (cache_off + 1024 <= 80 * 1024) {
         cache_groups = (80 * 1024 - cache_off) / 1024;
