@@ -421,20 +421,28 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
                     // image width is one too, every aligned group of 4 floats of the run lies inside one run of 4 pixels
                     // that are neighbours in memory and all inside or all outside the image: 16-byte stores.
                     if ((p.Wout & 3) == 0 && ((uintptr_t)p.y & 15) == 0) {
+                        // (row, column) of the lane's first element, then advanced by 256 elements per round with adds
+                        // and one wrap (a division per element costs more than the copy itself)
+                        int r0 = (int)(((float)(lane * 4) + 0.5f) * inv);
+                        int c0 = lane * 4 - r0 * nco;
+                        const int rstep = (int)((256.0f + 0.5f) * inv), cstep = 256 - rstep * nco;
                         for (int i = lane * 4; i < total; i += 256) {
                             f32x4 v;
-                            int r0 = 0, c0 = 0;
+                            int a = r0 * RSF + c0 * 4, cj = c0;
     #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const int r = (int)(((float)(i + j) + 0.5f) * inv);
-                                const int c = i + j - r * nco;
-                                if (j == 0) { r0 = r; c0 = c; }
-                                v[j] = *(const float *)(wreg + r * RSF + c * 4);
+                                v[j] = *(const float *)(wreg + a);
+                                const bool wrap = ++cj == nco;
+                                a += wrap ? RSF - (nco - 1) * 4 : 4;
+                                cj = wrap ? 0 : cj;
                             }
                             const int pq = wave * (32 * MREP) + m * 32 + r0;
                             const int qr = pq / TW, qc = pq % TW;
                             if (qr < p.TH && oh0 + qr < p.Hout && ow0 + qc < p.Wout)
                                 *(f32x4 *)((float *)p.y + ((size_t)(b * p.Hout + oh0 + qr) * p.Wout + ow0 + qc) * p.y_cs + c0) = v;
+                            c0 += cstep;
+                            r0 += rstep;
+                            if (c0 >= nco) { c0 -= nco; ++r0; }
                         }
                     } else
                     for (int i = lane; i < total; i += 64) {
