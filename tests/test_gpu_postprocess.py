@@ -279,3 +279,39 @@ def test_nms_bucket_larger_than_lds_sort_capacity(gpu_device):
     box = np.stack((rng.uniform(0, 640, n), rng.uniform(0, 640, n), rng.uniform(4, 30, n), rng.uniform(4, 30, n)), -1)
     score = rng.uniform(0.2, 0.9, n)
     _nms_case(gpu_device, _one_class_pred(box, score), 640.0)
+
+
+@pytest.mark.parametrize("n", [1000, 1030, 1100, 1500, 2047, 2100, 5800])
+def test_nms_group_counts_around_a_round_of_waves(gpu_device, n):
+    """One bucket of 16, 17, 18, 24, 32, 33 and 91 groups of 64 boxes: the sweep deals one group per wave and round, shares
+    the groups of the last partial round among the waves left over, keeps the boxes of a wave's first groups in registers,
+    the next ones in LDS and reads the rest from memory; every split must give the plain greedy result."""
+    rng = np.random.RandomState(n)
+    box = np.stack((rng.uniform(0, 640, n), rng.uniform(0, 640, n), rng.uniform(20, 120, n), rng.uniform(20, 120, n)), -1)
+    score = rng.uniform(0.2, 0.9, n)
+    kept = _nms_case(gpu_device, _one_class_pred(box, score), 640.0)
+    assert 0 < kept[0] < n
+
+
+def test_nms_more_oversized_buckets_than_compute_units(gpu_device):
+    """257+ images whose single bucket (8300 boxes) is beyond the LDS sort: with more such buckets than compute units they
+    run in the two-per-compute-unit instantiation of the sweep, otherwise in the other one; both against the C oracle
+    (every image holds the same boxes, so one oracle run checks them all)."""
+    from oracle import postprocess as pp
+    from yolo_amd import torch_utils as tu
+    rng = np.random.RandomState(5)
+    n = 8300
+    box = np.stack((rng.uniform(0, 640, n), rng.uniform(0, 640, n), rng.uniform(4, 40, n), rng.uniform(4, 40, n)), -1)
+    one = _one_class_pred(box, rng.uniform(0.2, 0.9, n))
+    want, want_idx = pp.non_max_suppression(one, 640.0, "cxcywh", 0.1, 0.3, return_index=True)
+    cus = torch.cuda.get_device_properties(gpu_device).multi_processor_count
+    for B in (3, cus + 4):
+        pred = torch.from_numpy(one).to(gpu_device).expand(B, -1, -1).contiguous()
+        rows, counts, index = tu.nms_batched(pred, 640.0, "cxcywh", 0.1, 0.3, 0, want_index=True)
+        k = want[0].shape[0]
+        assert counts.cpu().tolist() == [k] * B
+        r, ix = rows.cpu().numpy(), index.cpu().numpy()
+        for b in (0, B // 2, B - 1):
+            assert np.array_equal(r[b, :k].view(np.uint32), want[0].view(np.uint32))
+            assert np.array_equal(ix[b, :k].astype(np.int64), want_idx[0])
+        assert (r[:, :k] == r[0, :k]).all()
