@@ -556,13 +556,14 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
 
     // columns [4*wave, 4*wave+4) of tile `t`'s suppression matrix: bit j of column i = box i removes box j > i
     constexpr int CPW = 64 / SEG_WAVES;
-    auto phase_a = [&](u32 t, const float4 bx, const float ar) __attribute__((always_inline)) {
+    // `dead`: boxes of the tile that are already removed; a removed box suppresses nothing, its column is never read
+    auto phase_a = [&](u32 t, const float4 bx, const float ar, const u64 dead) __attribute__((always_inline)) {
         const u32 tn = min(64u, n - t * 64);
         const bool inr = (u32)lane < tn;
 #pragma unroll
         for (int ii = 0; ii < CPW; ++ii) {
             const int i = wave * CPW + ii;
-            if ((u32)i < tn) {
+            if ((u32)i < tn && !((dead >> i) & 1ull)) {
                 const float ix1 = rl(bx.x, i), iy1 = rl(bx.y, i), ix2 = rl(bx.z, i), iy2 = rl(bx.w, i), ia = rl(ar, i);
                 const bool sup = inr && lane > i && iou_gt(ix1, iy1, ix2, iy2, ia, bx.x, bx.y, bx.z, bx.w, ar, p.iou_thr);
                 const u64 cm = __ballot(sup);
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
     float4 bx = tile_box(0);                            // this lane's box of the current tile (by score rank)
     float ar = (bx.z - bx.x) * (bx.w - bx.y);
     __syncthreads();                                    // gbb/gmax/rem complete
-    phase_a(0, bx, ar);
+    phase_a(0, bx, ar, 0ull);
     u32 sp_cur = lane < (int)min(64u, n) ? posr[lane] : 0u;   // Morton position of this lane's tile box
     u64 key_cur = lane < (int)min(64u, n) ? skey[lane] : 0ull;
     __syncthreads();
@@ -625,7 +626,8 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             const u32 j = (t + 1) * 64 + lane;
             if (j < n) {
                 nbx = sbox[j];
-                if (wave == 0) { nsp = posr[j]; nkey = skey[j]; }
+                nsp = posr[j];
+                if (wave == 0) nkey = skey[j];
             }
         }
         if (nk > 0 && have_next) {
@@ -688,7 +690,9 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             ar = (bx.z - bx.x) * (bx.w - bx.y);
             sp_cur = nsp;
             key_cur = nkey;
-            phase_a(t + 1, bx, ar);
+            // what earlier tiles (and the part of this one's phase C that has landed) removed of the next tile
+            const bool gone = (t + 1) * 64 + lane < n && ((rem[nsp >> 6] >> (nsp & 63)) & 1ull);
+            phase_a(t + 1, bx, ar, __ballot(gone));
         }
         __syncthreads();
     }
