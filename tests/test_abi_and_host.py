@@ -204,7 +204,7 @@ def test_bottleneck_rewrite_of_the_recorded_ops():
     somewhere else, different activations, 128 channels) stay as they are."""
     import torch
     from yolo_amd import engine, lib as L, models
-    for name, n_fused in (("v5s", 5), ("v3", 1), ("v4", 3), ("v8s", 0), ("v5m", 0)):
+    for name, n_fused in (("v5s", 5), ("v3", 3), ("v4", 3), ("v8s", 0), ("v5m", 0)):
         p, m = models.create(name, img_size=128)
         prog = m.program()
         convs, macs, nbuf = prog.n_conv_launches(), prog.conv_macs_per_image(), len(prog.buffers)

@@ -419,5 +419,7 @@ extern "C" int yamd_bottleneck(int cin, int cmid, int cout, int act, const void 
     if (cin == 64 && cmid == 64) return launch_bneck_shape<64, 64, 64, 2, 4>(p, batch, st);
     if (cin == 64) return launch_bneck_shape<64, 32, 64, 1, 8>(p, batch, st);
     if (cmid == 128) return launch_bneck_shape<128, 128, 128, 1, 8>(p, batch, st);
-    return launch_bneck_shape<128, 64, 128, 1, 8>(p, batch, st);
+    // 128 > 64 > 128: 20-wide tiles of 12 rows keep the t image small enough for two workgroups per compute unit
+    if (p.act == YAMD_ACT_SILU) return launch_bneck<20, 128, 64, 128, 2, 4, YAMD_ACT_SILU>(p, batch, st);
+    return launch_bneck<20, 128, 64, 128, 2, 4, -1>(p, batch, st);
 }

@@ -180,9 +180,9 @@ class BottleneckLayer:
     """A 1x1 conv and the 3x3 conv that follows it (plus the unit's shortcut) run as one launch (``yamd_bottleneck``):
     the 1x1 conv's output is never written to memory."""
 
-    # (cin = cout, cmid) the plan fuses.  The library also builds (128, 128) and (128, 64); at those widths the unit is
-    # bound by arithmetic, not memory, and the two tuned launches are faster (207 against 243 us at 40 x 40, batch 256).
-    SHAPES = ((32, 32), (64, 64), (64, 32))
+    # (cin = cout, cmid) the plan fuses.  The library also builds (128, 128); at that width the unit is bound by
+    # arithmetic, not memory, and the two tuned launches are faster (207 against 243 us at 40 x 40, batch 256).
+    SHAPES = ((32, 32), (64, 64), (64, 32), (128, 64))
 
     def __init__(self, first: ConvLayer, second: ConvLayer):
         cmid, cin = first._w.shape[:2]
