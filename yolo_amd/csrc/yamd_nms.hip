@@ -197,7 +197,8 @@ __device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy
 
 constexpr int SEG_THREADS = 1024;           // 16 waves per bucket
 constexpr int SEG_WAVES = SEG_THREADS / 64;
-constexpr int CELLS = 4096;                 // grid cells of the spatial grouping
+constexpr int CELLS = 8192;                 // cells of the grouping: 2 size classes x 64 x 64 places
+constexpr int CELL_BITS = 13;
 
 // In-place bitonic sort, descending, of n (any n) 64-bit keys by one SEG_THREADS workgroup.  `a` may
 // point to LDS or to global memory.  The network only uses comparators that move the larger key to the
@@ -383,15 +384,19 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
     u32 *hist = (u32 *)smem_seg;                        // CELLS counters, then their exclusive prefix
     u32 *wsum = hist + CELLS;                           // SEG_WAVES wave totals
     auto cell_of = [&](float x1, float y1, float x2, float y2) __attribute__((always_inline)) {
+        // one bit of size class above 12 bits of place: boxes of very different size cannot overlap much (the IoU is at
+        // most the ratio of the areas), and a group of small boxes has a small bounding box that few kept boxes touch
         const u32 qx = (u32)fminf(fmaxf((x1 + x2) * 0.5f * qs, 0.0f), 1023.0f) >> 4;
         const u32 qy = (u32)fminf(fmaxf((y1 + y2) * 0.5f * qs, 0.0f), 1023.0f) >> 4;
-        return spread10(qx) | (spread10(qy) << 1);      // 12 bits
+        const float side2 = (x2 - x1) * (y2 - y1) * (qs * qs);          // area in units of (image / 1024)^2
+        const u32 sc = side2 > 96.0f * 96.0f;                           // sides beyond about a tenth of the image
+        return spread10(qx) | (spread10(qy) << 1) | (sc << 12);
     };
     auto scan_cells = [&]() __attribute__((always_inline)) {
         constexpr int PER = CELLS / SEG_THREADS;
-        u32 v[PER], sum = 0u;
+        u32 sum = 0u;                                   // (the counts are read again below: no register array)
 #pragma unroll
-        for (int i = 0; i < PER; ++i) { v[i] = hist[tid * PER + i]; sum += v[i]; }
+        for (int i = 0; i < PER; ++i) sum += hist[tid * PER + i];
         u32 inc = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -403,15 +408,18 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
         u32 run = inc - sum;
         for (int w = 0; w < wave; ++w) run += wsum[w];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) { hist[tid * PER + i] = run; run += v[i]; }
+        for (int i = 0; i < PER; ++i) {
+            const u32 c = hist[tid * PER + i];
+            hist[tid * PER + i] = run;
+            run += c;
+        }
     };
     if (in_lds) {
         // at most RPT ranks per thread (r = tid + 1024 q): keys, boxes, cells and tickets stay in registers, and the
         // scattered row reads of a thread are all in flight together
-        constexpr int RPT = 8192 / SEG_THREADS, RH = 2;
+        constexpr int RPT = 8192 / SEG_THREADS, RH = 1;
         u32 cq[RPT], tq[RPT];
-        // in two halves, so that the registers of the rows in flight (4 ranks x (key + 4 floats)) stay few enough for
-        // two workgroups per compute unit
+        // one rank at a time: the registers of more rows in flight would cost the second workgroup per compute unit
 #pragma unroll
         for (int h = 0; h < RPT / RH; ++h) {
             u64 kq[RH];
@@ -481,14 +489,14 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
         for (u32 r = tid; r < n; r += SEG_THREADS) {
             const u32 c = posr[r];
             const u32 t = atomicAdd(&hist[c], 1u);
-            posr[r] = c | (t << 12);                    // cell < 4096, ticket < n <= 2^18
+            posr[r] = c | (t << CELL_BITS);             // cell < 8192, ticket < n <= 2^18
         }
         __syncthreads();
         scan_cells();
         __syncthreads();
         for (u32 r = tid; r < n; r += SEG_THREADS) {
             const u32 v = posr[r];
-            const u32 sp = hist[v & (u32)(CELLS - 1)] + (v >> 12);
+            const u32 sp = hist[v & (u32)(CELLS - 1)] + (v >> CELL_BITS);
             mrank[sp] = r;
             posr[r] = sp;
             mbox[sp] = sbox[r];
