@@ -415,8 +415,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
         }
     };
     if (in_lds) {
-        // at most RPT ranks per thread (r = tid + 1024 q): keys, boxes, cells and tickets stay in registers, and the
-        // scattered row reads of a thread are all in flight together
+        // at most RPT ranks per thread (r = tid + 1024 q): cells and tickets stay in registers
         constexpr int RPT = 8192 / SEG_THREADS, RH = 1;
         u32 cq[RPT], tq[RPT];
         // one rank at a time: the registers of more rows in flight would cost the second workgroup per compute unit
