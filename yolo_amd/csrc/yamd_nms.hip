@@ -856,6 +856,11 @@ __global__ __launch_bounds__(256) void nms_rows_kernel(NmsParams p)
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) heads[it] = (sub < 5) ? pred[(b * p.A + idxs[it]) * (long long)p.C + sub] : 0.0f;
+    // ... and the lane's first class score of every row (all of them for up to 32 classes)
+    float cls_first[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+        cls_first[it] = (sub < p.nc) ? pred[(b * p.A + idxs[it]) * (long long)p.C + 5 + p.n_extra + sub] : 0.0f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const u32 r = rbase + it * 8 + grp;
@@ -871,10 +876,16 @@ __global__ __launch_bounds__(256) void nms_rows_kernel(NmsParams p)
         const float *cls0 = row + 5 + p.n_extra;
         float bv = -INFINITY;
         int bi = 0x7fffffff;
-        for (int c = sub; c < p.nc; c += 32) {
+        if (sub < p.nc) {
+            float v = cls_first[it];
+            if (sub > 0 && v != v) v = -INFINITY;
+            bv = v;
+            bi = sub;
+        }
+        for (int c = sub + 32; c < p.nc; c += 32) {
             float v = cls0[c];
-            if (c > 0 && v != v) v = -INFINITY;
-            if (c == sub || v > bv) { bv = v; bi = c; }
+            if (v != v) v = -INFINITY;
+            if (v > bv) { bv = v; bi = c; }
         }
 #pragma unroll
         for (int m = 16; m > 0; m >>= 1) {
