@@ -828,7 +828,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void nms_gather_sort_kernel(NmsPara
 // Output rows of the images ranked by nms_gather_sort_kernel: 32 lanes per row, many workgroups per image so the
 // dependent source-row loads of different rows overlap.  Lane c loads column c of the source row, the first-maximum
 // class is reduced across the lanes, and lanes 0..W-1 write the output columns of row `rank`.
-constexpr int ROWS_PER_BLOCK = 32;
+constexpr int ROWS_PER_BLOCK = 64;
 __global__ __launch_bounds__(256) void nms_rows_kernel(NmsParams p)
 {
     const long long b = blockIdx.y;
