@@ -75,7 +75,10 @@ def parse():
                          "process then belongs to a full-batch step)")
     ap.add_argument("--two-stream", action="store_true", help="NMS of step i on a second stream under step i+1's convs")
     ap.add_argument("--detail", default="", help="write the per-op timing table to this file")
-    ap.add_argument("--backend", default="nccl", help="process-group backend for the barriers (gloo for CPU rehearsal)")
+    ap.add_argument("--backend", default="gloo", choices=["gloo", "nccl"],
+                    help="process-group backend for the two barriers and the MAX over the ranks' times.  gloo (default) keeps "
+                         "them on the host: the data path has no collective, so RCCL never has to come up; nccl = RCCL")
+    ap.add_argument("--rank-timeout", type=float, default=900.0, help="seconds a rank waits for the others (rendezvous, barriers)")
     ap.add_argument("--dry", action="store_true", help="no GPU work: rehearse the multi-rank protocol only")
     return ap.parse_args()
 
@@ -84,22 +87,54 @@ def parse():
 # ranks
 def spawn_ranks(n: int) -> int:
     """WORLD_SIZE is not set and --gpus N > 1: start one child per GPU (fresh processes; this parent has made no GPU
-    call), relay rank 0's stdout, fail if any rank fails."""
+    call), relay rank 0's stdout and every rank's stderr, and fail as soon as any rank fails: the others are then ended
+    instead of waiting in a barrier for a rank that will never arrive."""
     import socket
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, errs = [], []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
+        errs.append(tempfile.TemporaryFile(mode="w+"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=errs[-1], text=True))
+    rcs = [None] * n
+    failed = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None:
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        rcs[r] = p.wait()
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    sys.stdout.write(out0.read())
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    for r, f in enumerate(errs):
+        f.seek(0)
+        text = f.read()
+        if text.strip():
+            sys.stderr.write("".join("[rank %d] %s\n" % (r, line) for line in text.splitlines()))
+    if failed is not None:
+        sys.stderr.write("rank %d exited with code %s; the other ranks were ended\n" % (failed, rcs[failed]))
+        return abs(rcs[failed]) or 1
+    return 0
 
 
 def dist_setup(args):
@@ -113,7 +148,9 @@ def dist_setup(args):
         if not args.dry:
             local %= max(1, torch.cuda.device_count())      # more ranks than GPUs (a rehearsal on one GPU): ranks share devices
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=args.rank_timeout))
     return world, rank, local
 
 
@@ -229,19 +266,50 @@ def candidate_stats(p, pred):
     return float(passed.sum(1).float().mean().item()), float((n * (n - 1) / 2).sum().item())
 
 
-def realistic_regime(args, p, model, images, sink, steps=5):
-    """Second NMS regime for the record: the same model with well-spread random weights and an objectness bias of
-    -5 on every head (what a trained detector looks like to NMS: O(10^2) candidates per image instead of all 25 200).
+def confidence_bias_keys(sd):
+    """The head-conv biases that set how many anchors pass the confidence filter, as (key, step): ``bias[4::step]`` is
+    the objectness logit of every anchor of an anchor-based head (v3 / v4 / v5 / v7, step = columns per anchor); step 0
+    = every element (the class-score conv of the anchor-free heads of v6 / v8)."""
+    import re
+    out = []
+    for k in sd:
+        if re.fullmatch(r"body_net\.(yolo_head_P\d|last_layer\d\.6|yolo_head\d\.1)\.bias", k):
+            out.append((k, sd[k].numel() // 3))
+        elif re.fullmatch(r"body_net\.cv3\.\d\.2\.bias|yolo_body\.head\.cls_predict_list\.\d\.bias", k):
+            out.append((k, 0))
+    return out
+
+
+def realistic_regime(args, p, model, images, sink, steps=5, target=300.0):
+    """Second NMS regime for the record: the same model with well-spread random weights and a negative bias on the
+    confidence logits of every head (what a trained detector looks like to NMS: O(10^2) candidates per image instead of
+    all anchors, or none at all).  The bias is the one of -2 ... -8 whose candidate count per image is nearest ``target``.
     Same step, same timing rule (rank-local; reported next to the headline, never as ``value``)."""
     from yolo_amd import models
     from yolo_amd.init import seeded_state_dict
-    sd = seeded_state_dict(model, seed=0, mode="spread", **models.init_options(args.model))
-    C = 5 + p.class_num
-    for k in sd:
-        if k.startswith("body_net.yolo_head_P") and k.endswith(".bias"):
-            sd[k] = sd[k].clone()
-            sd[k][4::C] -= 5.0
-    model.load_state_dict(sd)
+    base = seeded_state_dict(model, seed=0, mode="spread", **models.init_options(args.model))
+    keys = confidence_bias_keys(base)
+    if not keys:
+        return {"skipped": "no confidence bias found in this model's state_dict"}
+
+    def load(shift):
+        sd = dict(base)
+        for k, stepc in keys:
+            sd[k] = base[k].clone()
+            if stepc:
+                sd[k][4::stepc] -= shift
+            else:
+                sd[k] -= shift
+        model.load_state_dict(sd)
+
+    sub = images[:min(8, images.shape[0])]
+    best = None
+    for shift in (2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0):
+        load(shift)
+        cand, _ = candidate_stats(p, model.decode_predict(model.raw_heads(sub)))
+        if best is None or abs(np.log(max(cand, 1e-3) / target)) < abs(np.log(max(best[1], 1e-3) / target)):
+            best = (shift, cand)
+    load(best[0])
     for _ in range(2):
         step(model, images, sink)
     sink.drain()
@@ -254,9 +322,16 @@ def realistic_regime(args, p, model, images, sink, steps=5):
     dt = (time.perf_counter() - t0) / steps
     cand, _ = candidate_stats(p, model.decode_predict(model.raw_heads(images)))
     counts = np.diff(sink.h_offsets.numpy())
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    pred = model.decode_predict(model.raw_heads(images), model._arena)
+    ev[0].record()
+    model.nms_predict(pred, model._arena)
+    ev[1].record()
+    torch.cuda.synchronize()
     return {"images_per_s": round(images.shape[0] / dt, 1), "ms_per_step": round(dt * 1e3, 3),
             "candidates_per_image": round(cand, 1), "kept_per_image": round(float(counts.mean()), 1),
-            "weights": "spread random init, objectness bias -5 (seed 0)"}
+            "nms_ms": round(ev[0].elapsed_time(ev[1]), 3),
+            "weights": "spread random init, confidence-logit bias -%g (seed 0)" % best[0]}
 
 
 def two_stream_rate(model, images, sink, dev, steps):
@@ -373,20 +448,56 @@ def sustained_clock(load, dev, min_ms: float = 30.0):
             "load_ms_each": round(load_ms, 3)}
 
 
-def measured_conv_traffic(model_name: str, batch: int, n_conv: int):
+def measured_conv_traffic(model_name: str, batch: int, signature):
     """HBM bytes per conv launch from the committed PMC passes (profiles/*_conv_hbm_traffic.json, written by
-    scratch/pmc_conv.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command): counters cannot be
-    read from inside the process, so the latest committed measurement of the same workload is reported."""
+    scratch/layer_counters.sh from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs over the conv program of this same
+    workload): counters cannot be read from inside the process, so the latest committed measurement is reported --
+    but only one whose list of conv launches (layer, shape, tiling of every launch) equals the running plan's.  A file
+    measured on other kernels or tilings is refused and ``traffic`` stays null (the reason goes to ``traffic_source``)."""
     import glob
     if model_name != "v5s" or batch != 256:
         return None, None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_conv_hbm_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_conv_hbm_traffic.json")))      # names sort by round
+    reason = "no profiles/*_conv_hbm_traffic.json"
     for f in reversed(files):
         with open(f) as fh:
             d = json.load(fh)
-        if d.get("convs_per_pass") == n_conv:
+        if d.get("model") != model_name or d.get("batch") != batch:
+            continue
+        if d.get("conv_launches") == list(signature):
             return float(d["bytes_per_launch"]), os.path.relpath(f, ROOT)
-    return None, None
+        reason = ("refused %s: its conv launch list differs from the running plan's (re-measure with "
+                  "scratch/layer_counters.sh)" % os.path.relpath(f, ROOT))
+        break
+    return None, reason
+
+
+def h2d_rate(B: int, size: int, dev, ms_per_step: float, reps: int = 3):
+    """Host -> device feed of one rank's batch, outside the timed region (the timed steps start from images resident
+    in HBM): a page-locked host buffer copied to the device on the launch stream, timed with events, best of ``reps``.
+    Two forms: the float32 (B,3,S,S) tensor the reference's ``predict`` / ``YoloPredict.predict`` boundary hands over,
+    and the uint8 (B,S,S,3) frames the letterbox kernel of this library takes instead (a quarter of the bytes)."""
+    out = {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for key, shape, dtype in (("fp32_nchw", (B, 3, size, size), torch.float32), ("uint8_hwc", (B, size, size, 3), torch.uint8)):
+        host = torch.empty(shape, dtype=dtype).pin_memory()
+        host.view(torch.uint8).view(-1)[::4096] = 1          # touch every page
+        devbuf = torch.empty(shape, dtype=dtype, device=dev)
+        best = float("inf")
+        for _ in range(reps + 1):
+            e0.record()
+            devbuf.copy_(host, non_blocking=True)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        nbytes = host.numel() * host.element_size()
+        out[key] = {"bytes": nbytes, "ms": round(best, 3), "GBs": round(nbytes / (best * 1e-3) / 1e9, 2),
+                    "ms_over_step_ms": round(best / ms_per_step, 3)}
+        del host, devbuf
+    out["what"] = ("one rank's batch from page-locked host memory to the device, copy alone (events on the launch stream, "
+                   "best of %d); not part of `value`, whose steps start from HBM-resident images.  ms_over_step_ms > 1 means "
+                   "the link, not the GPU, would bound a pipeline fed in that form" % reps)
+    return out
 
 
 def cpu_baseline(name, sd, p):
@@ -428,6 +539,9 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    if os.environ.get("YAMD_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):      # test hook: this rank dies at start-up
+        print("rank %s: induced start-up failure" % os.environ.get("RANK", "0"), file=sys.stderr)
+        sys.exit(3)
     world, rank, local = dist_setup(args)
     scaling, sizes, starts, total_images = plan_batches(args, world)
     if args.dry:
@@ -492,7 +606,7 @@ def main():
         conv_tflops = prof["conv_flops"] / (conv_ms_pipe * 1e-3) / 1e12
         conv_tflops_iso = prof["conv_flops"] / (prof["conv_ms"] * 1e-3) / 1e12
         cand, pairs = candidate_stats(p, prof["pred"])
-        traffic, traffic_src = measured_conv_traffic(args.model, B, n_conv)
+        traffic, traffic_src = measured_conv_traffic(args.model, B, prog.conv_launch_signature())
         out = {
             "metric": METRIC, "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling,
@@ -541,6 +655,7 @@ def main():
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        out["h2d"] = h2d_rate(B, IMG, dev, ms_per_step)
         if not args.no_extras:
             peaks = measured_peaks(dev)
             out["measured_peaks"] = peaks
@@ -561,7 +676,7 @@ def main():
             out["conv_hbm"]["frac_of_measured_copy"] = round(out["conv_hbm"]["achieved_GBs"] / peaks["hbm_copy_GBs"], 4)
             if world == 1 and not args.two_stream:
                 out["two_stream"] = two_stream_rate(model, images, sink, dev, args.steps)
-            if args.model == "v5s" and world == 1:      # (loads other weights: keep it behind everything that needs the headline's)
+            if world == 1:      # (loads other weights: keep it behind everything that needs the headline's)
                 out["nms_regime_realistic"] = realistic_regime(args, p, model, images, sink)
             if world == 1:
                 del images, sink

@@ -47,7 +47,12 @@ int yamd_version(void);
  * kernel and device, safe from several host threads), so the call is only needed where that lazy step is unwanted:
  * before a region under HIP stream capture, or to take the one-off cost out of the first request.  Call it once per
  * device, with that device current.  No counterpart in the reference (PyTorch initialises its kernels the same lazy
- * way). */
+ * way).
+ * Stream capture: after this call (and one eager call that sizes the caller's buffers) the entry points record as kernel
+ * nodes only and allocate nothing.  ONE launch of the instantiated graph has been checked against the eager calls bit for
+ * bit; launching the same executable graph a second time ended in a GPU memory fault on ROCm 7.2 whose cause is not
+ * known, so repeated launches of a recorded step are NOT a supported use: issue the calls eagerly (they are
+ * asynchronous). */
 int yamd_init(void);
 
 /* ------------------------------------------------------------------------------------------

@@ -67,7 +67,7 @@ for op, us, s, f, w in zip(ops, dur, sq, fe, wr):
           f"{op['bytes'] / 1e6:8.1f} {(r + wv) / us * 1e3:7.0f}  {op['desc']}")
 n_conv = sum(1 for op in ops if op["kind"] in ("conv", "conv_cat2", "stem", "stem2", "bneck"))
 if len(sys.argv) > 2:
-    json.dump(dict(model=meta["model"], batch=meta["batch"], convs_per_pass=n_conv, read_bytes=tot["r"] * 1e6, write_bytes=tot["w"] * 1e6,
+    json.dump(dict(model=meta["model"], batch=meta["batch"], convs_per_pass=n_conv, conv_launches=meta.get("conv_launches"), read_bytes=tot["r"] * 1e6, write_bytes=tot["w"] * 1e6,
                    bytes_per_launch=(tot["r"] + tot["w"]) * 1e6 / n_conv, conv_us=tot["us"], conv_flops=tot["fl"],
                    mfma_busy_frac_at_2p4GHz=tot["busy"] / (tot["us"] * 1e-6 * 2.4e9 * 1024),
                    note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES in separate passes over the conv "

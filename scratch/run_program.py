@@ -31,4 +31,4 @@ for op in prog.ops:
         desc = f"1x1 + 3x3 + shortcut {op[1].cin}>{op[1].cmid}>{op[1].cout} @{op[3].h}x{op[3].w}"
     launches = 1
     ops.append(dict(kind=kind, name=name_, desc=desc, flops=fl, bytes=by))
-json.dump(dict(model=name, batch=B, reps=reps, ops=ops), open(out, "w"))
+json.dump(dict(model=name, batch=B, reps=reps, ops=ops, conv_launches=prog.conv_launch_signature()), open(out, "w"))

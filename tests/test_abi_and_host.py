@@ -262,3 +262,46 @@ def test_plan_follows_weights_loaded_through_a_submodule():
     assert m.program() is prog3
     p.anchors = [[a[0] + 1, a[1]] for a in p.anchors]
     assert m.program() is not prog3
+
+
+def test_service_selects_its_device_before_any_library_call(monkeypatch):
+    """``ManagePredict(gpu_id)``: a non-zero gpu_id addresses that ordinal unless the streamer's visibility mask
+    (CUDA_VISIBLE_DEVICES = gpu_id) has made it ordinal 0, and every call that reaches the library runs with that device
+    current (the library launches on the current device's stream and keeps per-device state by the current device)."""
+    import contextlib
+    from yolo_amd import service
+    for var in ("CUDA_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert service.ManagePredict(gpu_id=None).device == torch.device("cuda", 0)
+    assert service.ManagePredict(gpu_id=3).device == torch.device("cuda", 3)
+    monkeypatch.setenv("CUDA_VISIBLE_DEVICES", "3")
+    assert service.ManagePredict(gpu_id=3).device == torch.device("cuda", 0)       # masked: the one visible device
+    assert service.ManagePredict(gpu_id=2).device == torch.device("cuda", 2)       # not the streamer's convention
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES")
+
+    current = []
+
+    @contextlib.contextmanager
+    def fake_device(dev):
+        current.append(torch.device(dev))
+        try:
+            yield
+        finally:
+            current.pop()
+
+    monkeypatch.setattr(torch.cuda, "device", fake_device)
+
+    class Session:
+        def _forward(self, images):
+            assert current and current[-1] == torch.device("cuda", 5), "library reached without the device selected"
+            return [images.sum(dim=(2, 3))]
+
+    class Probe(service.ManagePredict):
+        def _upload(self, array):
+            assert current and current[-1] == torch.device("cuda", 5)
+            return torch.as_tensor(array, dtype=torch.float32)
+
+    sp = Probe(gpu_id=5)
+    sp.session, sp.outputs = Session(), ["head_predicts"]
+    out = sp.sess_predict({"images": np.ones((2, 3, 4, 4), dtype=np.float32)})
+    assert out.shape == (2, 3) and not current

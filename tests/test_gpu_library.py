@@ -1,6 +1,7 @@
 """Library-surface checks on the GPU: explicit and lazy per-device set-up, NMS from two host threads, the NMS paths
 for very many kept rows / very many classes (bit-exact against the C oracle), a whole predict_device step captured
-into a HIP graph and replayed, and argument checks that must fail before any kernel runs."""
+into a HIP graph and launched once (opt-in), and argument checks that must fail before any kernel runs."""
+import os
 import threading
 
 import numpy as np
@@ -115,12 +116,15 @@ def test_rejects_images_that_are_not_rgb(gpu_device):
             m._forward(torch.zeros(shape, device=gpu_device))
 
 
+@pytest.mark.skipif(os.environ.get("YAMD_TEST_HIP_GRAPH") != "1",
+                    reason="opt-in (YAMD_TEST_HIP_GRAPH=1): launching recorded steps is not a supported use, and a second "
+                           "launch of one executable graph has faulted the GPU on ROCm 7.2 for a reason that is not known")
 def test_predict_device_captured_as_hip_graph(gpu_device):
     """conv graph -> decode -> NMS recorded into a HIP graph: the step allocates nothing and sets nothing up while it is
-    recorded (persistent arenas, yamd_init), and the launch of the recorded graph equals the eager step bit for bit.
-    Each recorded graph is launched ONCE here: on this ROCm build a second launch of the same executable graph ends in a
-    GPU memory fault although the first is bit-identical to eager and eager steps repeat indefinitely
-    (profiles/r2_hipgraph_second_replay_fault.log), so the test stays on the side that is known to be safe."""
+    recorded (persistent arenas, yamd_init, kernel nodes only), and the launch of the recorded graph equals the eager
+    step bit for bit.  Each recorded graph is launched ONCE here: on this ROCm build a second launch of the same
+    executable graph ended in a GPU memory fault although the first is bit-identical to eager and eager steps repeat
+    indefinitely (profiles/r2_hipgraph_second_replay_fault.log).  Not part of the default GPU suite."""
     from yolo_amd import lib as L, models
     from yolo_amd.init import seeded_images, seeded_state_dict
     torch.cuda.set_device(gpu_device)

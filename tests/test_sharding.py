@@ -43,6 +43,17 @@ def test_worker_processes_shard_and_gather_in_image_order():
         _same(sp.predict(pred), want)
         _same(sp.predict(pred[:2]), want[:2])          # fewer images than workers: one worker gets an empty slice
         _same(sp.predict(pred[3:]), want[3:])
+        # the producer writes straight into the workers' shared blocks; a larger batch makes the blocks grow
+        big = H.make_pred(batch=11, seed=5)
+        views = sp.input_views(big.shape[0], big.shape[1:], big.dtype)
+        assert [v.shape[0] for v in views] == [4, 4, 3]
+        for v, sl in zip(views, parallel.shard_slices(big.shape[0], 3)):
+            v[...] = big[sl]
+        _same(sp.predict_views(), H.oracle_nms(big))
+        _same(sp.predict(pred), want)                  # and back to the smaller one in the grown blocks
+        paths = [b.path for b in sp._blocks]
+        assert all(os.path.exists(q) for q in paths)
+    assert not any(os.path.exists(q) for q in paths), "shared blocks must be unlinked on close"
 
 
 def test_worker_start_failure_is_reported():

@@ -70,3 +70,35 @@ def test_static_scratch_nms_refuses_oversized_input(gpu_device):
                                        dummy.data_ptr(), L.current_stream())
     assert rc == -3
     assert b"static" in L.LIB.yamd_last_error()
+
+
+def test_static_scratch_nms_allocates_nothing(gpu_device):
+    """The property the entry point exists for: after one warm-up call, a call changes neither the free device memory
+    the driver reports nor torch's allocation counter.  yamd_init resolves the static array on every visible device and
+    fails unless its address is 256-byte aligned there."""
+    from oracle.gen_golden_synth import synthetic_pred
+    from yolo_amd import lib as L
+    for d in range(torch.cuda.device_count()):
+        with torch.cuda.device(d):
+            assert L.LIB.yamd_init() == 0, L.LIB.yamd_last_error()
+    torch.cuda.set_device(gpu_device)
+    B, A, nc = 3, 4000, 20
+    pred = torch.from_numpy(synthetic_pred(np.random.RandomState(91), B, A, nc, 640.0, clusters=30)).to(gpu_device)
+    rows = torch.empty((B, A, 7), dtype=torch.float32, device=gpu_device)
+    index = torch.empty((B, A), dtype=torch.int32, device=gpu_device)
+    counts = torch.empty((B,), dtype=torch.int32, device=gpu_device)
+    st = L.current_stream()
+
+    def call():
+        L.check(L.LIB.yamd_nms_batched_static(pred.data_ptr(), B, A, 5 + nc, 1, 0, 640.0, 0.1, 0.3, rows.data_ptr(),
+                                              index.data_ptr(), A, counts.data_ptr(), st), "nms_batched_static")
+        torch.cuda.synchronize()
+
+    call()                                                     # warm-up: code objects loaded, attributes raised
+    free0 = torch.cuda.mem_get_info(gpu_device)[0]
+    n0 = torch.cuda.memory_stats(gpu_device)["allocation.all.allocated"]
+    for _ in range(3):
+        call()
+    assert torch.cuda.mem_get_info(gpu_device)[0] == free0, "free device memory changed across static-scratch calls"
+    assert torch.cuda.memory_stats(gpu_device)["allocation.all.allocated"] == n0
+    assert int(counts.sum()) > 0

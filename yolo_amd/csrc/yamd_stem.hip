@@ -6,6 +6,10 @@
 // Bias + activation, then the tile leaves through LDS as whole NHWC pixel rows.
 #include "yamd_conv_kernel.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 using namespace yamd;
 
 namespace {
@@ -186,14 +190,18 @@ constexpr int F_IFRAG = (F_IPIX + 31) / 32;
 constexpr int F_HALF = (F_IC + 1) / 2;                      // a row of stem pixels is stored even columns first, then odd:
 constexpr int F_CROW = 2 * F_HALF;                          // the stride-2 taps of neighbouring outputs are neighbours in LDS
 
-// Tile counters of the fused launches: a ring of 256 per GPU, each launch zeroes and uses the next one (on its stream), so
-// launches that overlap on one GPU -- other streams, other host threads -- do not share a counter unless 256 of them are
-// in flight at once.  The array's name is a host-side handle only; every device has its own copy at its own address.
+// Tile counters of the fused launches: 256 pairs {next tile, workgroups done} per GPU.  A pair belongs to one stream of
+// that GPU (stream_ticket): launches on one stream run one after the other, and the last workgroup of a launch to finish
+// puts both words back to zero, so a pair is zero whenever a launch starts and nothing but the kernel ever writes it (no
+// memset on the stream: a recorded step holds kernel nodes only).  Launches on different streams use different pairs, so
+// they may overlap; only when more than 256 streams of one GPU have launched do streams share a pair, and such streams
+// must not run this kernel at the same time.  A step recorded into a HIP graph keeps the pair of the stream it was
+// recorded on: do not launch the graph while that stream runs fused-stem launches of its own.
+// The array's name is a host-side handle only; every device has its own copy at its own address.
 constexpr int TICKET_RING = 256;
 constexpr int TICKET_MAX_DEVICES = 64;
 std::atomic<unsigned *> g_ticket_base[TICKET_MAX_DEVICES];
-std::atomic<unsigned> g_ticket_seq{0};
-int next_ticket(unsigned **out);
+int stream_ticket(hipStream_t st, unsigned **out);
 
 template <int KS, int S>
 struct FusedGeom {
@@ -220,7 +228,8 @@ struct FusedParams {
     const float *b2;
     __bf16 *y;
     int H, W, H1, W1, H2, W2, C2, y_cs, act1, act2, tiles_x, tiles_y, total_tiles;
-    unsigned *ticket;      // zero at launch: tiles after a workgroup's first are handed out by this counter
+    unsigned *ticket;      // ticket[0]: tiles after a workgroup's first are handed out by this counter; ticket[1]: workgroups
+                           // that have finished.  Both zero at launch; the last workgroup to finish zeroes them again
 };
 
 // ACTK >= 0: both activations are that kind, fixed at compile time (SiLU for v5 / v8, ReLU for the re-parameterised v6
@@ -307,8 +316,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
     // up with a fixed share.  Thread 0 draws the ticket one tile ahead, so its latency is never waited for.
     int *s_next = (int *)(w2s + W2_BYTES);
     int tile = blockIdx.x;
-    if (tile >= p.total_tiles) return;
     int ticket = 0;
+    if (tile < p.total_tiles) {
     if (tid == 0) ticket = (int)gridDim.x + (int)atomicAdd(p.ticket, 1u);
     load_patch(tile);
     for (;;) {
@@ -441,6 +450,16 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
         if (next >= p.total_tiles) break;
         tile = next;
     }
+    }
+    // Every workgroup reports in once all its draws from the tile counter have returned (the release orders them before
+    // the report); the one whose report is the last of the grid zeroes both words for the next launch on this stream.
+    if (tid == 0) {
+        const unsigned done = __hip_atomic_fetch_add(p.ticket + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.ticket + 1, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 template <int KS, int S, int NREP1, int NREP2, int ACTK>
@@ -468,10 +487,9 @@ int launch_stem_conv2_act(const FusedParams &p, hipStream_t st)
     if (grid > p.total_tiles) grid = p.total_tiles;
     FusedParams q = p;
     {
-        const int rc = next_ticket(&q.ticket);
+        const int rc = stream_ticket(st, &q.ticket);
         if (rc != YAMD_OK) return rc;
     }
-    YAMD_HIP(hipMemsetAsync(q.ticket, 0, sizeof(unsigned), st));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS, st, q);
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
@@ -487,10 +505,10 @@ int launch_stem_conv2(const FusedParams &p, hipStream_t st)
 
 }  // namespace
 
-static __device__ __align__(256) unsigned stem_tickets[256];
+static __device__ __align__(256) unsigned stem_tickets[2 * TICKET_RING];
 
 namespace {
-int next_ticket(unsigned **out)
+int ticket_base(int *dev_out, unsigned **base_out)
 {
     int dev = 0;
     YAMD_HIP(hipGetDevice(&dev));
@@ -503,7 +521,25 @@ int next_ticket(unsigned **out)
         base = (unsigned *)ptr;
         g_ticket_base[dev].store(base, std::memory_order_release);
     }
-    *out = base + (g_ticket_seq.fetch_add(1u, std::memory_order_relaxed) % TICKET_RING);
+    *dev_out = dev;
+    *base_out = base;
+    return YAMD_OK;
+}
+
+// the counter pair of stream `st` on the current device: assigned on the stream's first launch, kept for the process
+int stream_ticket(hipStream_t st, unsigned **out)
+{
+    int dev = 0;
+    unsigned *base = nullptr;
+    const int rc = ticket_base(&dev, &base);
+    if (rc != YAMD_OK) return rc;
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, int> slots;
+    static int used[TICKET_MAX_DEVICES];
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = slots.find({dev, st});
+    if (it == slots.end()) it = slots.emplace(std::make_pair(dev, st), used[dev]++ % TICKET_RING).first;
+    *out = base + 2 * it->second;
     return YAMD_OK;
 }
 
@@ -513,8 +549,9 @@ namespace yamd {
 int stem_init_current_device(int device)
 {
     (void)device;
-    unsigned *t = nullptr;
-    return next_ticket(&t);
+    int dev = 0;
+    unsigned *base = nullptr;
+    return ticket_base(&dev, &base);
 }
 }  // namespace yamd
 

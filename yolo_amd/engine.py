@@ -511,6 +511,22 @@ class Program:
     def n_conv_launches(self) -> int:
         return sum(1 for op in self.ops if op[0] in ("conv", "conv_cat2", "stem", "stem2", "bneck"))
 
+    def conv_launch_signature(self) -> List[str]:
+        """One string per conv launch of a pass, in launch order: kind, layer name, shape and tiling.  Two plans with the
+        same list launch the same kernels on the same shapes (what a stored per-launch measurement has to match)."""
+        sig = []
+        for op in self.ops:
+            kind = op[0]
+            if kind in ("conv", "conv_cat2"):
+                d = op[1].desc
+                o = op[3] if kind == "conv" else op[6]
+                sig.append(f"{kind} {op[1].name} k{d.ksize}s{d.stride} {d.cin}>{d.cout} @{o.h}x{o.w} tiling={op[1].tiling}")
+            elif kind == "bneck":
+                sig.append(f"bneck {op[1].name} {op[1].cin}>{op[1].cmid}>{op[1].cout} @{op[3].h}x{op[3].w}")
+            elif kind in ("stem", "stem2"):
+                sig.append(f"{kind} {op[1].name} @{op[2].h}x{op[2].w}")
+        return sig
+
     def conv_macs_per_image(self) -> int:
         total = 0
         for op in self.ops:

@@ -119,9 +119,9 @@ class TaskModel(nn.Module):
 
         Activations, the decoded tensor, the NMS scratch and both results live in buffers that persist between
         calls (``Program`` arena + ``self._arena``): a call with the same batch size allocates nothing and writes
-        to the same addresses as the one before, so the results are valid until the next call on this model, and
-        the call can be recorded into a HIP graph (after one eager call, which sizes the buffers and sets up the
-        kernels) and replayed."""
+        to the same addresses as the one before, so the results are valid until the next call on this model.
+        (The call also records into a HIP graph as kernel nodes only, but launching one such graph repeatedly is
+        not supported: see ``yamd_init`` in include/yolo_amd.h.)"""
         return self.nms_predict(self.decode_predict(self.raw_heads(images), self._arena), self._arena)
 
     def fuse(self):

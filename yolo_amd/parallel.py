@@ -54,6 +54,75 @@ def gather_predicts_to_rank0(local: Sequence[Optional[np.ndarray]], group=None) 
     return gather_predicts(bucket) if rank == 0 else None
 
 
+class SharedBatch:
+    """A block of host memory shared between the parent and one worker through a file in /dev/shm (plain ``mmap`` on
+    both sides; no pickling, no pipe).  The parent writes a slice of images into it, the worker reads them from the
+    same pages -- after ``pin()`` as page-locked memory, so the copy to the device is one DMA transfer."""
+
+    def __init__(self, path: str, nbytes: int, create: bool):
+        import mmap
+        import os
+        self.path, self.nbytes = path, int(nbytes)
+        fd = os.open(path, (os.O_CREAT | os.O_EXCL | os.O_RDWR) if create else os.O_RDWR, 0o600)
+        try:
+            if create:
+                os.ftruncate(fd, self.nbytes)
+            self._map = mmap.mmap(fd, self.nbytes)
+        finally:
+            os.close(fd)
+        self.owner = create
+        self.pinned = False
+
+    @staticmethod
+    def new_path(tag: str) -> str:
+        import os
+        import tempfile
+        import uuid
+        root = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+        return os.path.join(root, f"yolo_amd_{os.getpid()}_{tag}_{uuid.uuid4().hex[:12]}")
+
+    def array(self, shape, dtype=np.float32) -> np.ndarray:
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if n > self.nbytes:
+            raise ValueError(f"{tuple(shape)} {np.dtype(dtype)} needs {n} bytes, the block holds {self.nbytes}")
+        return np.frombuffer(self._map, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def pin(self) -> bool:
+        """Page-locks the mapping for the GPU runtime of the calling process (hipHostRegister); False when the runtime
+        refuses (the copy then goes through the runtime's own staging buffer)."""
+        import ctypes
+        import torch
+        if self.pinned or self.nbytes == 0:
+            return self.pinned
+        addr = ctypes.addressof(ctypes.c_char.from_buffer(self._map))
+        try:
+            self.pinned = int(torch.cuda.cudart().cudaHostRegister(addr, self.nbytes, 0)) == 0
+        except Exception:       # noqa: BLE001
+            self.pinned = False
+        self._addr = addr
+        return self.pinned
+
+    def close(self) -> None:
+        import os
+        if self.pinned:
+            import torch
+            try:
+                torch.cuda.cudart().cudaHostUnregister(self._addr)
+            except Exception:   # noqa: BLE001
+                pass
+            self.pinned = False
+        try:
+            self._map.close()
+        except (BufferError, ValueError):       # a numpy view is still alive: the pages go with the last reference
+            pass
+        if self.owner:
+            try:
+                os.unlink(self.path)
+            except FileNotFoundError:
+                pass
+            self.owner = False
+
+
 class ModelRunner:
     """Default per-device worker body: builds the model from ``model_factory()`` on its GPU and maps a float32
     (n,3,S,S) host array to the reference's ``predicts`` list through ``TaskLayer.predict``."""
@@ -70,7 +139,8 @@ class ModelRunner:
         def run(images: np.ndarray) -> List[Optional[np.ndarray]]:
             if images.shape[0] == 0:
                 return []
-            x = torch.from_numpy(np.ascontiguousarray(images, dtype=np.float32)).to(dev)
+            # (a view of the shared, page-locked block when it comes from ShardedPredictor: one DMA transfer)
+            x = torch.from_numpy(np.ascontiguousarray(images, dtype=np.float32)).to(dev, non_blocking=True)
             return model.predict({"batch_images": x})["predicts"]
 
         return run
@@ -83,13 +153,24 @@ def _worker(device: str, runner_factory, in_q, out_q) -> None:
     except BaseException:       # noqa: BLE001  (reported to the parent, which raises)
         out_q.put(("error", traceback.format_exc()))
         return
+    block: Optional[SharedBatch] = None
     while True:
         job = in_q.get()
         if job is None:
+            if block is not None:
+                block.close()
             return
-        ticket, images = job
+        ticket, path, nbytes, shape, dtype = job
         try:
-            out_q.put(("done", (ticket, run(images))))
+            if block is None or block.path != path:
+                if block is not None:
+                    block.close()
+                block = SharedBatch(path, nbytes, create=False)
+                block.pin()
+            images = block.array(shape, dtype)
+            result = run(images)
+            del images
+            out_q.put(("done", (ticket, result)))
         except BaseException:   # noqa: BLE001
             out_q.put(("error", traceback.format_exc()))
             return
@@ -98,6 +179,11 @@ def _worker(device: str, runner_factory, in_q, out_q) -> None:
 class ShardedPredictor:
     """One worker process per device; ``predict(images)`` splits the batch into contiguous slices, runs them
     concurrently and returns the per-image list in the original order.
+
+    Images reach a worker through a block of shared host memory (``SharedBatch``: the parent writes the slice, the
+    worker has the same pages page-locked and copies them to its GPU), not through the queue; the queues carry only
+    the job header and the kept rows.  ``input_views(n, shape)`` hands out the blocks themselves, for a producer that
+    can write its images where the workers read them (no copy in the parent at all); ``predict_views()`` then runs them.
 
     ``runner_factory(device) -> callable(images ndarray) -> List[Optional[ndarray]]`` is executed inside each worker
     (it must be picklable: a module-level function, a ``functools.partial`` of one, or a ``ModelRunner``).
@@ -117,6 +203,9 @@ class ShardedPredictor:
         for p in self._procs:
             p.start()
         self._ticket = 0
+        self._blocks: List[Optional[SharedBatch]] = [None] * len(self.devices)
+        self._retired: List[SharedBatch] = []
+        self._views = None
         try:
             for d, q in zip(self.devices, self._out):
                 kind, payload = q.get(timeout=start_timeout)
@@ -126,12 +215,31 @@ class ShardedPredictor:
             self.close()
             raise
 
-    def predict(self, images: np.ndarray, timeout: float = 600.0) -> List[Optional[np.ndarray]]:
-        images = np.asarray(images)
-        slices = shard_slices(images.shape[0], len(self.devices))
+    def input_views(self, batch: int, image_shape: Sequence[int], dtype=np.float32) -> List[np.ndarray]:
+        """Per worker, a writable ``(n_r, *image_shape)`` array in that worker's shared block, ``n_r`` the size of its
+        contiguous slice of a batch of ``batch`` images (rank order = image order).  Fill them, then ``predict_views()``."""
+        slices = shard_slices(batch, len(self.devices))
+        views = []
+        for r, sl in enumerate(slices):
+            shape = (sl.stop - sl.start,) + tuple(int(v) for v in image_shape)
+            need = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            blk = self._blocks[r]
+            if blk is None or blk.nbytes < need:
+                if blk is not None:
+                    self._retired.append(blk)      # unlinked once the worker has moved to the new block
+                blk = SharedBatch(SharedBatch.new_path(f"w{r}"), max(need, 1), create=True)
+                self._blocks[r] = blk
+            views.append(blk.array(shape, dtype))
+        self._views = (views, dtype)
+        return views
+
+    def predict_views(self, timeout: float = 600.0) -> List[Optional[np.ndarray]]:
+        if self._views is None:
+            raise RuntimeError("input_views() has not been called")
+        views, dtype = self._views
         self._ticket += 1
-        for q, sl in zip(self._in, slices):
-            q.put((self._ticket, images[sl]))
+        for q, blk, v in zip(self._in, self._blocks, views):
+            q.put((self._ticket, blk.path, blk.nbytes, v.shape, np.dtype(dtype).str))
         parts = []
         for d, q in zip(self.devices, self._out):
             kind, payload = q.get(timeout=timeout)
@@ -142,7 +250,17 @@ class ShardedPredictor:
             if ticket != self._ticket:
                 raise RuntimeError(f"worker for {d} answered request {ticket}, expected {self._ticket}")
             parts.append(part)
+        for blk in self._retired:
+            blk.close()
+        self._retired = []
         return gather_predicts(parts)
+
+    def predict(self, images: np.ndarray, timeout: float = 600.0) -> List[Optional[np.ndarray]]:
+        images = np.asarray(images)
+        views = self.input_views(images.shape[0], images.shape[1:], images.dtype)
+        for v, sl in zip(views, shard_slices(images.shape[0], len(self.devices))):
+            np.copyto(v, images[sl])
+        return self.predict_views(timeout)
 
     def close(self) -> None:
         for q, p in zip(self._in, self._procs):
@@ -156,12 +274,22 @@ class ShardedPredictor:
             if p.is_alive():
                 p.terminate()
         self._procs = []
+        self._views = None
+        for blk in list(self._retired) + [b for b in self._blocks if b is not None]:
+            blk.close()
+        self._retired, self._blocks = [], [None] * len(self.devices)
 
     def __enter__(self):
         return self
 
     def __exit__(self, *exc):
         self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001
+            pass
 
 
 def predict_sharded(model_factory: Callable[[], Any], images: np.ndarray, devices: Sequence[str]

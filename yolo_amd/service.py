@@ -36,7 +36,27 @@ class ManagePredict(object):
         self.outputs = NotImplemented
         self.config_dict: Dict[str, Any] = NotImplemented
         self.restore_size = RestoreSize()
-        self.device = torch.device("cuda", 0 if gpu_id in (None, -1) else int(gpu_id))
+        self.device = torch.device("cuda", self.device_ordinal(gpu_id))
+
+    @staticmethod
+    def device_ordinal(gpu_id: Union[int, None]) -> int:
+        """The device ordinal inside this process for the streamer's ``gpu_id``.  ``service_streamer.ManagedModel``
+        workers select their GPU by masking visibility (``CUDA_VISIBLE_DEVICES = gpu_id`` before ``init_model``), after
+        which the one visible device is ordinal 0; a caller that masks nothing addresses the device by ``gpu_id``."""
+        if gpu_id in (None, -1):
+            return 0
+        for var in ("CUDA_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+            if os.environ.get(var, "").strip() == str(int(gpu_id)):
+                return 0
+        return int(gpu_id)
+
+    def _on_device(self):
+        """Makes ``self.device`` current for the calling thread: the library launches on the current device's stream and
+        looks its per-device state up by the current device, so every call into it runs inside this context."""
+        return torch.cuda.device(self.device)
+
+    def _upload(self, array) -> torch.Tensor:
+        return torch.as_tensor(array, dtype=torch.float32).to(self.device).contiguous()
 
     @staticmethod
     def checkpoint_path(model_dir: str, onnx_name: str) -> str:
@@ -55,8 +75,9 @@ class ManagePredict(object):
             config_dict = json.load(f)
         path = self.checkpoint_path(model_dir, config_dict["onnx_name"])
         sd = torch.load(path, map_location="cpu", weights_only=True)
-        _, self.session = _models.from_state_dict(sd, int(config_dict["input_size"]), int(config_dict.get("output_size", 0)),
-                                                  int(kwargs.get("point_num", 0)))
+        with self._on_device():
+            _, self.session = _models.from_state_dict(sd, int(config_dict["input_size"]), int(config_dict.get("output_size", 0)),
+                                                      int(kwargs.get("point_num", 0)))
         self.config_dict = config_dict
 
     def predict(self, feed_dicts: List[Dict[str, Any]]):
@@ -65,8 +86,8 @@ class ManagePredict(object):
     def sess_run(self, outputs: List[str], feed_dict: Dict[str, np.ndarray]) -> List[np.ndarray]:
         if list(outputs) != ["head_predicts"]:
             raise KeyError(f"the exported graph has one output, 'head_predicts'; asked for {outputs}")
-        images = torch.as_tensor(feed_dict["images"], dtype=torch.float32).to(self.device).contiguous()
-        return [self.session._forward(images)[0].cpu().numpy()]
+        with self._on_device():
+            return [self.session._forward(self._upload(feed_dict["images"]))[0].cpu().numpy()]
 
     def sess_predict(self, feed_dict: Dict[str, np.ndarray]):
         return self.sess_run(outputs=self.outputs, feed_dict=feed_dict)[0]
@@ -109,8 +130,9 @@ class YoloPredict(ManagePredict):
         self.labels = c["lables"]
         mean, std = c.get("mean", None), c.get("std", None)
         if mean is not None and std is not None:          # ImageNorm normalises only when both are given (:213-218)
-            self.mean = torch.tensor(mean, dtype=torch.float32, device=self.device).view(1, 3, 1, 1)
-            self.std = torch.tensor(std, dtype=torch.float32, device=self.device).view(1, 3, 1, 1)
+            with self._on_device():
+                self.mean = torch.tensor(mean, dtype=torch.float32, device=self.device).view(1, 3, 1, 1)
+                self.std = torch.tensor(std, dtype=torch.float32, device=self.device).view(1, 3, 1, 1)
         # warm-up request, as the reference sends one (its outcome is only reported there, :55-62)
         n = int(kwargs.get("batch_size", 1))
         self.sess_predict(feed_dict={"images": np.zeros((n, 3, self.input_size[0], self.input_size[0]), dtype=np.float32)})
@@ -118,15 +140,17 @@ class YoloPredict(ManagePredict):
     def predict(self, feed_dicts: List[Dict[str, Any]]) -> List[Any]:
         if not self.nms:
             raise NotImplementedError("config.json has nms = false: the reference has no such path either")
-        images, metas = letterbox_batch([_decode_image(d["image"]) for d in feed_dicts], self.input_size[0],
-                                        self.input_size[1], device=self.device)
-        if self.mean is not None:
-            images = (images - self.mean) / self.std
-        pred = self.session._forward(images)[0]
-        rows, counts, _ = torch_utils.nms_batched(pred, self.input_size[0], "cxcywh", self.conf_threshold,
-                                                  self.nms_threshold, 0)
+        with self._on_device():
+            images, metas = letterbox_batch([_decode_image(d["image"]) for d in feed_dicts], self.input_size[0],
+                                            self.input_size[1], device=self.device)
+            if self.mean is not None:
+                images = (images - self.mean) / self.std
+            pred = self.session._forward(images)[0]
+            rows, counts, _ = torch_utils.nms_batched(pred, self.input_size[0], "cxcywh", self.conf_threshold,
+                                                      self.nms_threshold, 0)
+            host_rows = torch_utils.rows_to_host(rows, counts)
         outputs = []
-        for feed_dict, meta, nms_predicts in zip(feed_dicts, metas, torch_utils.rows_to_host(rows, counts)):
+        for feed_dict, meta, nms_predicts in zip(feed_dicts, metas, host_rows):
             feed_dict.update(meta)
             feed_dict["predict"] = nms_predicts
             self.restore_size.transformer(data_dict=feed_dict)

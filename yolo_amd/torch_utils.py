@@ -35,7 +35,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 class Arena:
     """Named device buffers that persist between calls, so that a step re-uses the same addresses every time
-    (no allocator traffic per batch, and a step recorded into a HIP graph replays onto memory it still owns).
+    (no allocator traffic per batch; a step recorded under stream capture writes to memory the model still owns).
     A buffer is re-allocated only when its shape, dtype or device changes."""
 
     def __init__(self):
