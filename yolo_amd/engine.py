@@ -123,6 +123,7 @@ class StemLayer:
         self.name, self.mode, self.act, self.cout, self.cin_real = name, self.MODES[mode], act, cout, cin_real
         self.macs_per_pixel = cout * cin_real * 9
         b = None if bias is None else bias.detach().to(torch.float32).cpu().contiguous()
+        self._w, self._b = w, b
         n = LIB.yamd_stem_packed_elems(self.mode, cout)
         if n <= 0:
             raise _lib.YamdError(f"stem[{name}]: cout={cout} not supported")
@@ -150,6 +151,7 @@ class StemConv2Layer:
         self.stem, self.name, self.act, self.cout, self.cin_real = stem, name, act, cout, cin
         self.macs_per_pixel = cout * cin * 9
         b = None if bias is None else bias.detach().to(torch.float32).cpu().contiguous()
+        self._w, self._b = w, b
         n = LIB.yamd_stem_conv2_packed_elems(cin, cout)
         if n <= 0:
             raise _lib.YamdError(f"stem_conv2[{name}]: cin={cin} cout={cout} not supported")

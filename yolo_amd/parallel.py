@@ -57,7 +57,9 @@ def gather_predicts_to_rank0(local: Sequence[Optional[np.ndarray]], group=None) 
 class SharedBatch:
     """A block of host memory shared between the parent and one worker through a file in /dev/shm (plain ``mmap`` on
     both sides; no pickling, no pipe).  The parent writes a slice of images into it, the worker reads them from the
-    same pages -- after ``pin()`` as page-locked memory, so the copy to the device is one DMA transfer."""
+    same pages into a page-locked staging buffer of its own, from which the copy to the device is one DMA transfer.
+    (Registering the shared mapping itself with the GPU runtime, hipHostRegister, would save that hop; the runtime
+    of ROCm 7.2 refused copies from a mapping registered that way with hipErrorInvalidValue.)"""
 
     def __init__(self, path: str, nbytes: int, create: bool):
         import mmap
@@ -71,7 +73,6 @@ class SharedBatch:
         finally:
             os.close(fd)
         self.owner = create
-        self.pinned = False
 
     @staticmethod
     def new_path(tag: str) -> str:
@@ -87,30 +88,8 @@ class SharedBatch:
             raise ValueError(f"{tuple(shape)} {np.dtype(dtype)} needs {n} bytes, the block holds {self.nbytes}")
         return np.frombuffer(self._map, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
-    def pin(self) -> bool:
-        """Page-locks the mapping for the GPU runtime of the calling process (hipHostRegister); False when the runtime
-        refuses (the copy then goes through the runtime's own staging buffer)."""
-        import ctypes
-        import torch
-        if self.pinned or self.nbytes == 0:
-            return self.pinned
-        addr = ctypes.addressof(ctypes.c_char.from_buffer(self._map))
-        try:
-            self.pinned = int(torch.cuda.cudart().cudaHostRegister(addr, self.nbytes, 0)) == 0
-        except Exception:       # noqa: BLE001
-            self.pinned = False
-        self._addr = addr
-        return self.pinned
-
     def close(self) -> None:
         import os
-        if self.pinned:
-            import torch
-            try:
-                torch.cuda.cudart().cudaHostUnregister(self._addr)
-            except Exception:   # noqa: BLE001
-                pass
-            self.pinned = False
         try:
             self._map.close()
         except (BufferError, ValueError):       # a numpy view is still alive: the pages go with the last reference
@@ -136,11 +115,20 @@ class ModelRunner:
         torch.cuda.set_device(dev)
         model = self.model_factory()
 
+        staging = {}
+
         def run(images: np.ndarray) -> List[Optional[np.ndarray]]:
             if images.shape[0] == 0:
                 return []
-            # (a view of the shared, page-locked block when it comes from ShardedPredictor: one DMA transfer)
-            x = torch.from_numpy(np.ascontiguousarray(images, dtype=np.float32)).to(dev, non_blocking=True)
+            # shared block -> page-locked staging buffer (kept between calls) -> device
+            src = torch.from_numpy(np.ascontiguousarray(images, dtype=np.float32))
+            buf = staging.get("pinned")
+            if buf is None or buf.numel() < src.numel():
+                buf = torch.empty(src.numel(), dtype=torch.float32).pin_memory()
+                staging["pinned"] = buf
+            host = buf[:src.numel()].view(src.shape)
+            host.copy_(src)
+            x = host.to(dev, non_blocking=True)
             return model.predict({"batch_images": x})["predicts"]
 
         return run
@@ -166,7 +154,6 @@ def _worker(device: str, runner_factory, in_q, out_q) -> None:
                 if block is not None:
                     block.close()
                 block = SharedBatch(path, nbytes, create=False)
-                block.pin()
             images = block.array(shape, dtype)
             result = run(images)
             del images
@@ -181,7 +168,7 @@ class ShardedPredictor:
     concurrently and returns the per-image list in the original order.
 
     Images reach a worker through a block of shared host memory (``SharedBatch``: the parent writes the slice, the
-    worker has the same pages page-locked and copies them to its GPU), not through the queue; the queues carry only
+    worker copies it through its own page-locked buffer to its GPU), not through the queue; the queues carry only
     the job header and the kept rows.  ``input_views(n, shape)`` hands out the blocks themselves, for a producer that
     can write its images where the workers read them (no copy in the parent at all); ``predict_views()`` then runs them.
 
