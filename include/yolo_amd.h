@@ -74,7 +74,8 @@ typedef struct yamd_conv_desc {
     float residual_scale;     /* y = act(..) + residual_scale * residual; yamd_conv_desc_init sets 1 (the learned
                                * shortcut weight ``alpha`` of BottleRep, yolov6/YoloV6Body.py:451-472) */
     int32_t stages;           /* 1: one LDS image of the staged input chunk; 2: two, filled alternately (one barrier per
-                               * chunk instead of two) */
+                               * chunk instead of two), a workgroup walks every cout tile of its pixel tile; 3: as 2, one
+                               * cout tile per workgroup (the workgroups of a pixel tile share its input through L2) */
 } yamd_conv_desc;
 
 int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int cin, int cout, int act, int out_f32);
@@ -82,7 +83,7 @@ int yamd_conv_desc_init(yamd_conv_desc *d, int ksize, int stride, int cin, int c
 /* Optional: override the tiling chosen by yamd_conv_desc_init (per-layer tuning) before the weights are packed.
  * mrep in {1,2}: 128 or 256 output pixels per workgroup; nrep in {1,2,4}: 32*nrep output channels per workgroup;
  * ck in {16,32,64}: input channels staged per step; nwaves in {4,8}: wavefronts per workgroup, i.e. the pixel tile
- * is nwaves*32*mrep pixels; stages in {1,2}: LDS images of the staged chunk.  Fails if that kernel is not built.  No
+ * is nwaves*32*mrep pixels; stages in {1,2,3}: see yamd_conv_desc.  Fails if that kernel is not built.  No
  * counterpart in the reference (MIOpen picks its own algorithm there). */
 int yamd_conv_desc_tune(yamd_conv_desc *d, int mrep, int nrep, int ck, int nwaves, int stages);
 

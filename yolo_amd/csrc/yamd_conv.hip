@@ -95,12 +95,12 @@ extern "C" int yamd_conv_desc_tune(yamd_conv_desc *d, int mrep, int nrep, int ck
 {
     YAMD_REQUIRE(d != nullptr, "null descriptor");
     YAMD_REQUIRE(nwaves == 4 || nwaves == 8, "nwaves=%d must be 4 or 8", nwaves);
-    YAMD_REQUIRE(stages == 1 || stages == 2, "stages=%d must be 1 or 2", stages);
+    YAMD_REQUIRE(stages >= 1 && stages <= 3, "stages=%d must be 1, 2 or 3", stages);
     YAMD_REQUIRE((mrep == 1 || mrep == 2) && (nrep == 1 || nrep == 2 || nrep == 4) && (ck == 16 || ck == 32 || ck == 64),
                  "bad tiling mrep=%d nrep=%d ck=%d", mrep, nrep, ck);
     YAMD_REQUIRE(d->cin % ck == 0, "cin=%d is not a multiple of ck=%d", d->cin, ck);
     YAMD_REQUIRE(!d->out_f32, "the float-output kernel has one tiling");
-    YAMD_REQUIRE(is_built(d->ksize, d->stride, mrep, nrep, ck, 0, nwaves, stages),
+    YAMD_REQUIRE(is_built(d->ksize, d->stride, mrep, nrep, ck, 0, nwaves, stages == 3 ? 2 : stages),
                  "no kernel built for k=%d s=%d mrep=%d nrep=%d ck=%d nwaves=%d stages=%d", d->ksize, d->stride, mrep, nrep, ck,
                  nwaves, stages);
     d->mrep = mrep;
@@ -316,7 +316,8 @@ int conv_impl(const yamd_conv_desc *d, const void *x, int x_cstride, const void 
     p.oW = orig_w;
     hipStream_t st = (hipStream_t)stream;
 
-    const int stages = d->stages == 2 ? 2 : 1;
+    const int stages = d->stages >= 2 ? 2 : 1;      // LDS images; stages 3 = two images, one cout tile per workgroup
+    p.ntw = d->stages == 2 ? p.n_tiles : 1;
     YAMD_REQUIRE(is_built(KS, S, d->mrep, d->nrep, d->ck, d->out_f32, d->nwaves, stages),
                  "no conv kernel built for k=%d s=%d mrep=%d nrep=%d ck=%d f32=%d nwaves=%d stages=%d", KS, S, d->mrep, d->nrep,
                  d->ck, d->out_f32, d->nwaves, stages);

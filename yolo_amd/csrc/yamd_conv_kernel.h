@@ -46,6 +46,9 @@ struct ConvParams {
     int TH, tiles_x, tiles_y, n_tiles, nchunks;
     int act;
     int total_tiles;
+    int ntw;                     // two-image form: cout tiles a workgroup walks (n_tiles: all of them; 1: one, the grid then
+                                 // holds n_tiles workgroups per pixel tile, neighbours in the XCD's tile range, so that
+                                 // they read the same activations through one L2)
     // stacked mode (3x3, bf16 output): the images of the batch are treated as ONE tall image, `vin` input rows and
     // `vout` output rows per image (the real rows followed by 1 or 2 rows of zero padding, which is exactly the
     // padding the neighbouring images need), so tiles are not confined to one image and small feature maps still
@@ -177,8 +180,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
     YAMD_STAMP(0);
     // one image: a workgroup owns one cout tile of one pixel tile.  Two images: it owns the pixel tile and walks its
     // cout tiles one after the other (the chunk stream simply continues into the next cout tile's weights)
-    const int nt0 = STAGES == 2 ? 0 : bid % p.n_tiles;
-    if constexpr (STAGES != 2) bid /= p.n_tiles;
+    const int ngrp = STAGES == 2 ? p.n_tiles / p.ntw : p.n_tiles;      // workgroups per pixel tile
+    const int nt0 = (bid % ngrp) * (STAGES == 2 ? p.ntw : 1);         // first cout tile of this workgroup
+    bid /= ngrp;
     const int tx = bid % p.tiles_x;
     bid /= p.tiles_x;
     const int ty = bid % p.tiles_y;
@@ -618,10 +622,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
         // behind.  The very last chunks reload the final chunk again and store pieces nobody reads: no branch inside
         // the pipeline.
         constexpr int NSLOT = TAPS * KSTEPS, NPIECE = WP + AP;
-        const int last = p.n_tiles * p.nchunks - 1;      // index of the final chunk of the stream
+        const int last = p.ntw * p.nchunks - 1;          // index of the final chunk of the stream
         {
             const int l1 = min(1, last), c1 = l1 % p.nchunks;
-            const char *wsrc = p.w + (size_t)l1 * WBYTES;
+            const char *wsrc = wtile + (size_t)l1 * WBYTES;
             static_for<WP>([&](auto uc) __attribute__((always_inline)) {
                 constexpr int u = decltype(uc)::value;
                 rw[u] = *(const u32x4 *)(wsrc + min(tid + u * NT, WBYTES / 16 - 1) * 16);
@@ -635,8 +639,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
         int gi = 0;                                               // chunks computed so far
         __syncthreads();
         YAMD_STAMP(2);
-        for (int nt = 0; nt < p.n_tiles; ++nt) {
-            if (nt > 0) init_acc(nt);
+        for (int nt = nt0; nt < nt0 + p.ntw; ++nt) {
+            if (nt > nt0) init_acc(nt);
             for (int ch = 0; ch < p.nchunks; ++ch, ++gi) {
 #ifdef YAMD_CONV_TRACE
                 if (gi == 1) YAMD_STAMP(5);
@@ -645,7 +649,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
                 const int cur = (gi & 1) * stage_bytes;
                 char *nxtW = smem + (stage_bytes - cur);
                 char *nxtA = nxtW + WBYTES;
-                const char *wsrc = p.w + (size_t)lnext * WBYTES;
+                const char *wsrc = wtile + (size_t)lnext * WBYTES;
                 compute_chunk(cur, [&](auto sc) __attribute__((always_inline)) {
                     constexpr int slot = decltype(sc)::value;
                     constexpr int u0 = slot * NPIECE / NSLOT, u1 = (slot + 1) * NPIECE / NSLOT;
@@ -670,10 +674,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
             }
             // the image just computed from is free; the other one already holds the next cout tile's first chunk
 #ifdef YAMD_CONV_TRACE
-            if (nt + 1 == p.n_tiles) YAMD_STAMP(3);
+            if (nt + 1 == nt0 + p.ntw) YAMD_STAMP(3);
 #endif
             finish_tile(nt, smem + ((gi & 1) ^ 1) * stage_bytes);
-            if (nt + 1 < p.n_tiles) __syncthreads();   // the next chunk stages into the image the epilogue used
+            if (nt + 1 < nt0 + p.ntw) __syncthreads();   // the next chunk stages into the image the epilogue used
         }
     } else {
         __syncthreads();
@@ -728,7 +732,7 @@ int launch_conv(const ConvParams &p, int batch, hipStream_t stream)
         const int rc = KernelAttr<&conv_igemm_kernel<KS, S, TW, MREP, NREP, CK, OUT_F32, ACTK, NW, STAGES>, 160 * 1024>::ensure();
         if (rc != YAMD_OK) return rc;
     }
-    const long long total = (long long)batch * p.tiles_y * p.tiles_x * (STAGES == 2 ? 1 : p.n_tiles);
+    const long long total = (long long)batch * p.tiles_y * p.tiles_x * (STAGES == 2 ? p.n_tiles / p.ntw : p.n_tiles);
     YAMD_REQUIRE(total > 0 && total < (1ll << 31) - 8, "conv grid out of range");
     YAMD_REQUIRE((long long)(p.vout > 0 ? p.vbatch : batch) * p.Hout * p.Wout < (1ll << 31), "more than 2^31 output pixels in one launch");
     ConvParams q = p;

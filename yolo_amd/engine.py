@@ -446,7 +446,7 @@ class Program:
                 log(f"{layer.name:34s} {key:28s} " + "  ".join(f"{c}={t:.4f}" for t, c in results[:5]))
         return best
 
-    def autotune_in_situ(self, images: torch.Tensor, reps: int = 7, log=None) -> Dict[str, Tuple[int, ...]]:
+    def autotune_in_situ(self, images: torch.Tensor, reps: int = 7, log=None, only: str = "") -> Dict[str, Tuple[int, ...]]:
         """Like ``autotune``, but every candidate tiling is timed inside a run of the whole program (events around the
         layers of that shape), so its inputs come from where the previous layer left them (HBM or L2) and not from a
         cache warmed by running the same layer back to back.  Starts from the tilings the layers currently have."""
@@ -474,6 +474,8 @@ class Program:
         best: Dict[str, Tuple[int, ...]] = {}
         self.run(images)
         for key, members in groups.items():
+            if only and not key.startswith(only):
+                continue
             names = {m[0].name for m in members}
             _, k, s, cin, cout = members[0]
             start = members[0][0].tiling

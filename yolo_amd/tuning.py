@@ -46,7 +46,9 @@ def candidates(k: int, s: int, cin: int, cout: int) -> List[Tuple[int, ...]]:
             for ck in (16, 32, 64):
                 if cin % ck == 0:
                     for nwaves in (4, 8):
-                        for stages in (1, 2):
+                        for stages in (1, 2, 3):
+                            if stages == 3 and groups <= nrep:       # one cout tile: the same launch as stages 2
+                                continue
                             out.append((mrep, nrep, ck, nwaves, stages))
     return out
 
@@ -83,7 +85,7 @@ def main() -> None:
     imgs = torch.rand(args.batch, 3, p.img_size, p.img_size, device=dev)
     prog.run(imgs)                                     # fill the buffers with real activations
     if args.in_situ:
-        best = prog.autotune_in_situ(imgs, reps=args.reps, log=print)
+        best = prog.autotune_in_situ(imgs, reps=args.reps, log=print, only=args.only)
     else:
         skip = set(table()) if args.missing_only else set()
         if args.only:
