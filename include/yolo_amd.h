@@ -337,6 +337,26 @@ int yamd_bottleneck(int cin, int cmid, int cout, int act, const void *x, int x_c
                     const float *bias_packed, int shortcut, void *y, int y_cstride, int batch, int h, int w, void *stream);
 
 /* ----------------------------------------------------------------------------------------
+ * A whole C3 block with one bottleneck in one launch (yolov5/YoloV5Body.py:96-111, C3.forward with n = 1, over
+ * Bottleneck :80-93):
+ *     y = cv3(cat((m(cv1(x)), cv2(x)), 1)),   m(a) = a + m.cv2(m.cv1(a)) (shortcut) or m.cv2(m.cv1(a))
+ * every conv followed by its folded BatchNorm bias and SiLU.  Same result as the layer-by-layer path (1x1 conv to the
+ * two branches, yamd_bottleneck, 1x1 conv over the concatenation; every intermediate tensor rounded to bf16 in both,
+ * fp32 accumulation in a different order), but x is read once and y written once: the four tensors in between never
+ * reach memory.  Built for (cin, ch, cout) = (64, 32, 64), the 160 x 160 stage of YOLOv5-s (dark2), SiLU only.
+ * Weights fp32 with BN folded: w_cv1, w_cv2 (ch, cin, 1, 1); w_m1 (ch, ch, 1, 1); w_m2 (ch, ch, 3, 3); w_cv3
+ * (cout, 2*ch, 1, 1) with input channels ordered [m | cv2 branch] as the reference's cat.  The pack call writes
+ * yamd_c3_packed_elems() bf16 values and 4*ch + cout floats.  x, y: NHWC bf16, disjoint tensors or different channel
+ * slices of one buffer.
+ * ---------------------------------------------------------------------------------------- */
+int64_t yamd_c3_packed_elems(int cin, int ch, int cout);   /* 0 = this shape is not built */
+int yamd_c3_pack_weights(int cin, int ch, int cout, const float *w_cv1, const float *b_cv1, const float *w_cv2,
+                         const float *b_cv2, const float *w_m1, const float *b_m1, const float *w_m2, const float *b_m2,
+                         const float *w_cv3, const float *b_cv3, void *w_packed_host, float *bias_packed_host);
+int yamd_c3_fused(int cin, int ch, int cout, int act, const void *x, int x_cstride, const void *w_packed,
+                  const float *bias_packed, int shortcut, void *y, int y_cstride, int batch, int h, int w, void *stream);
+
+/* ----------------------------------------------------------------------------------------
  * A model's whole conv graph as one call.  Replaces `out5, out4, out3 = self.body_net(images)`, the module-by-module
  * forward of the backbone + neck + head convs (yolov5/YoloV5.py:54 and :79 over yolov5/YoloV5Body.py:159-187,
  * :223-260; the same statement in every other model class), for callers that do not want one foreign call per layer.
@@ -365,7 +385,8 @@ enum {
     YAMD_OP_COPY_CHANNELS = 12,   /* yamd_copy_channels over batch*h*w pixels: i = {x_cstride, y_cstride, h, w, c} */
     YAMD_OP_CONV_CAT2 = 13,       /* yamd_conv2d_bias_act_cat2: desc; p[0] = xa, p[3] = xb, p[5] = y2 or NULL;
                                    * i = {xa_cstride, xb_cstride, y_cstride, h, w, y2_cstride, split_cout, ca, xa_half | xb_half << 1} */
-    YAMD_OP_BOTTLENECK = 14       /* yamd_bottleneck: i = {x_cstride, cin, y_cstride, h, w, cmid, cout, act, shortcut} */
+    YAMD_OP_BOTTLENECK = 14,      /* yamd_bottleneck: i = {x_cstride, cin, y_cstride, h, w, cmid, cout, act, shortcut} */
+    YAMD_OP_C3 = 15               /* yamd_c3_fused: i = {x_cstride, cin, y_cstride, h, w, ch, cout, act, shortcut} */
 };
 typedef struct yamd_plan_op {
     int32_t kind;

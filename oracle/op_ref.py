@@ -9,6 +9,7 @@ What an op restates from the reference:
                      (YoloV5Body.py:80-93, DarkNet53.py:10-47; weighted by ``alpha`` in yolov6/YoloV6Body.py:451-472), and
                      ``torch.cat((nn.Upsample(2)(a), b), 1)`` in front of a 1x1 conv (YoloV5Body.py:232-240)
   bneck              Bottleneck cv1 -> cv2 (+ x) (YoloV5Body.py:80-93)
+  c3                 C3.forward with one Bottleneck (YoloV5Body.py:96-111)
   stem / stem2       Focus + conv (YoloV5Body.py:54-77) or the first 3x3 conv, and the 3x3 stride-2 conv after it
   mp5 / mp2 / up2    nn.MaxPool2d(k, 1, k // 2) chains of SPP / SPPF (YoloV5Body.py:114-132, yolov8/YoloV8Body.py:102-114),
                      MP (YoloV7PoseBody.py:76-82), nn.Upsample(scale_factor=2, mode="nearest")
@@ -89,6 +90,17 @@ def op_reference(op, read: Callable, images: torch.Tensor) -> Dict[str, Tuple[to
         if shortcut:
             y = y + xin
         return {f"bneck {layer.name}": (y, read(out), False)}
+    if kind == "c3":
+        _, layer, x, out, shortcut = op
+        le, lu, lx = layer.entry, layer.unit, layer.exit
+        ch = layer.ch
+        ab = bf16(_conv(read(x)[:, :le.cin_real], le._w, le._b, 1, le._args[4]))       # channels [cv2 | cv1]
+        b, a = ab[:, :ch], ab[:, ch:]
+        t = bf16(_conv(a, lu.first._w, lu.first._b, 1, lu.first._args[4]))
+        u = _conv(t, lu.second._w, lu.second._b, 1, lu.second._args[4])
+        m = bf16(a + u if shortcut else u)
+        y = _conv(torch.cat((m, b), 1), lx._w, lx._b, 1, lx._args[4])
+        return {f"c3 {layer.name}": (y, read(out), False)}
     if kind == "stem":
         _, layer, out = op
         return {f"stem {layer.name}": (stem_ref(layer, images), read(out), False)}

@@ -59,13 +59,13 @@ for op, us, s, f, w in zip(ops, dur, sq, fe, wr):
     act = s.get("SQ_ACTIVE_INST_ANY", 0.0) / wc * 100
     r = f.get("FETCH_SIZE", 0.0) * 1024 * 2 / 1e6
     wv = w.get("WRITE_SIZE", 0.0) * 1024 / 1e6
-    is_conv = op["kind"] in ("conv", "conv_cat2", "stem", "stem2", "bneck")
+    is_conv = op["kind"] in ("conv", "conv_cat2", "stem", "stem2", "bneck", "c3")
     if is_conv:
         for k, v in (("us", us), ("fl", op["flops"]), ("busy", busy), ("r", r), ("w", wv), ("alg", op["bytes"] / 1e6)):
             tot[k] += v
     print(f"{op['kind']:5s} {op['name'][:34]:34s} {us:8.1f} {op['flops'] / us / 1e6:7.1f} {mf:6.1f} {wait:6.1f} {ldsw:6.1f} {park:6.1f} {act:6.1f} {r:8.1f} {wv:8.1f} "
           f"{op['bytes'] / 1e6:8.1f} {(r + wv) / us * 1e3:7.0f}  {op['desc']}")
-n_conv = sum(1 for op in ops if op["kind"] in ("conv", "conv_cat2", "stem", "stem2", "bneck"))
+n_conv = sum(1 for op in ops if op["kind"] in ("conv", "conv_cat2", "stem", "stem2", "bneck", "c3"))
 if len(sys.argv) > 2:
     json.dump(dict(model=meta["model"], batch=meta["batch"], convs_per_pass=n_conv, conv_launches=meta.get("conv_launches"), read_bytes=tot["r"] * 1e6, write_bytes=tot["w"] * 1e6,
                    bytes_per_launch=(tot["r"] + tot["w"]) * 1e6 / n_conv, conv_us=tot["us"], conv_flops=tot["fl"],

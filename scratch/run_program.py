@@ -21,12 +21,14 @@ ops = []
 for op in prog.ops:
     fl, by = prog.op_cost(op, B)
     kind = op[0]
-    name_ = getattr(op[1], "name", kind) if kind in ("conv", "conv_cat2", "stem", "stem2", "bneck") else kind
+    name_ = getattr(op[1], "name", kind) if kind in ("conv", "conv_cat2", "stem", "stem2", "bneck", "c3") else kind
     desc = ""
     if kind in ("conv", "conv_cat2"):
         d = op[1].desc
         o = op[3] if kind == "conv" else op[6]
         desc = f"k{d.ksize}s{d.stride} {d.cin}>{d.cout} @{o.h}x{o.w} tiling={op[1].tiling}"
+    if kind == "c3":
+        desc = f"C3 block (1x1 x2, 1x1 + 3x3 + shortcut, 1x1) {op[1].cin}>{op[1].ch}>{op[1].cout} @{op[3].h}x{op[3].w}"
     if kind == "bneck":
         desc = f"1x1 + 3x3 + shortcut {op[1].cin}>{op[1].cmid}>{op[1].cout} @{op[3].h}x{op[3].w}"
     launches = 1

@@ -665,3 +665,70 @@ def test_bottleneck_fused(gpu_device, cin, cmid, H, W, act, shortcut, batch):
                                  1, 4, 4, L.current_stream()) != 0
     assert L.LIB.yamd_bottleneck(cin, cmid, cout, act, xin.data_ptr() + in_extra * 2, xin.shape[-1], wd.data_ptr(), bd.data_ptr(),
                                  0, xin.data_ptr() + in_extra * 2, xin.shape[-1], batch, H, W, L.current_stream()) != 0
+
+
+@pytest.mark.parametrize("H,W,shortcut,batch", [(160, 160, 1, 2), (24, 40, 1, 3), (17, 19, 0, 2), (8, 16, 1, 1), (5, 3, 1, 2),
+                                                (33, 160, 0, 1)])
+def test_c3_block_fused(gpu_device, H, W, shortcut, batch):
+    """yamd_c3_fused (a whole C3 block with one bottleneck in one launch) against the launches it replaces -- the 1x1 conv
+    to both branches, yamd_bottleneck, the 1x1 conv over [bottleneck output | other branch] -- and against fp32 torch
+    on the CPU with every intermediate tensor rounded to bf16.  The fused kernel accumulates in another order (channel
+    order of the chained layers), so the bound is the conv bound, not bit identity; image borders (the 3x3 conv pads
+    the inner 1x1 conv's output), partial tiles, images smaller than one tile and channel slices of wider buffers."""
+    from yolo_amd import lib as L
+    cin, ch, cout, act = 64, 32, 64, 1
+    g = torch.Generator().manual_seed(H * 131 + W)
+    x = _bf16_round(torch.randn(batch, cin, H, W, generator=g))
+    w_cv1 = torch.randn(ch, cin, 1, 1, generator=g) / cin ** 0.5
+    w_cv2 = torch.randn(ch, cin, 1, 1, generator=g) / cin ** 0.5
+    w_m1 = torch.randn(ch, ch, 1, 1, generator=g) / ch ** 0.5
+    w_m2 = torch.randn(ch, ch, 3, 3, generator=g) / (3 * ch ** 0.5)
+    w_cv3 = torch.randn(cout, 2 * ch, 1, 1, generator=g) / (2 * ch) ** 0.5
+    b_cv1, b_cv2, b_m1, b_m2 = (torch.randn(ch, generator=g) * 0.5 for _ in range(4))
+    b_cv3 = torch.randn(cout, generator=g) * 0.5
+
+    # fp32 reference, intermediates rounded to bf16 as both GPU paths store / keep them
+    rb = _bf16_round
+    conv = lambda t, w, b, k: _act(F.conv2d(t, rb(w), b, padding=k // 2), act)      # noqa: E731
+    a, b_ = rb(conv(x, w_cv1, b_cv1, 1)), rb(conv(x, w_cv2, b_cv2, 1))
+    u = conv(rb(conv(a, w_m1, b_m1, 1)), w_m2, b_m2, 3)
+    m = rb(a + u if shortcut else u)
+    want = conv(torch.cat((m, b_), 1), w_cv3, b_cv3, 1)
+
+    # the launches the fused one replaces
+    a_g = _run_conv(gpu_device, x, w_cv1, b_cv1, 1, 1, act)
+    b_g = _run_conv(gpu_device, x, w_cv2, b_cv2, 1, 1, act)
+    t_g = _run_conv(gpu_device, a_g, w_m1, b_m1, 1, 1, act)
+    m_g = _run_conv(gpu_device, t_g, w_m2, b_m2, 3, 1, act, res=a_g if shortcut else None)
+    apart = _run_conv(gpu_device, torch.cat((m_g, b_g), 1), w_cv3, b_cv3, 1, 1, act)
+
+    n = L.LIB.yamd_c3_packed_elems(cin, ch, cout)
+    assert n > 0 and L.LIB.yamd_c3_packed_elems(128, 64, 128) == 0
+    wp = torch.empty(n, dtype=torch.int16)
+    bp = torch.empty(4 * ch + cout, dtype=torch.float32)
+    ws = [t.contiguous() for t in (w_cv1, b_cv1, w_cv2, b_cv2, w_m1, b_m1, w_m2, b_m2, w_cv3, b_cv3)]
+    L.check(L.LIB.yamd_c3_pack_weights(cin, ch, cout, *[t.data_ptr() for t in ws], wp.data_ptr(), bp.data_ptr()))
+    wd, bd = wp.to(gpu_device), bp.to(gpu_device)
+    in_extra, out_extra = 8, 16
+    xin = torch.full((batch, H, W, cin + in_extra), 7.0, dtype=torch.bfloat16)
+    xin[..., in_extra:] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    xin = xin.to(gpu_device)
+    y = torch.full((batch, H, W, cout + out_extra), -3.0, dtype=torch.bfloat16, device=gpu_device)
+    L.check(L.LIB.yamd_c3_fused(cin, ch, cout, act, xin.data_ptr() + in_extra * 2, xin.shape[-1], wd.data_ptr(), bd.data_ptr(),
+                                shortcut, y.data_ptr() + out_extra * 2, y.shape[-1], batch, H, W, L.current_stream()), "c3_fused")
+    torch.cuda.synchronize()
+    yc = y.cpu().float()
+    assert torch.all(yc[..., :out_extra] == -3.0), "wrote outside its channel slice"
+    got = yc[..., out_extra:].permute(0, 3, 1, 2)
+    rel = lambda p_, q_: float((p_ - q_).norm() / q_.norm())      # noqa: E731
+    assert rel(got, want) <= 6e-3, rel(got, want)
+    assert rel(got, apart) <= 6e-3, rel(got, apart)
+    assert float((got - want).abs().max()) <= 3e-2 * float(want.abs().max())
+    # borders separately: an indexing slip there hides in the total
+    for sl in (np.s_[:, :, 0], np.s_[:, :, -1], np.s_[:, :, :, 0], np.s_[:, :, :, -1]):
+        assert rel(got[sl], want[sl]) <= 8e-3
+    # refusals: other activations, and an output that overlaps the input
+    assert L.LIB.yamd_c3_fused(cin, ch, cout, 2, xin.data_ptr(), cin + in_extra, wd.data_ptr(), bd.data_ptr(), 0, y.data_ptr(),
+                               y.shape[-1], batch, H, W, L.current_stream()) != 0
+    assert L.LIB.yamd_c3_fused(cin, ch, cout, act, xin.data_ptr() + in_extra * 2, xin.shape[-1], wd.data_ptr(), bd.data_ptr(), 0,
+                               xin.data_ptr() + in_extra * 2, xin.shape[-1], batch, H, W, L.current_stream()) != 0

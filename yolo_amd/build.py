@@ -30,6 +30,7 @@ SOURCES = [
     ("yamd_metric.hip", ["-ffp-contract=off"]),
     ("yamd_stem.hip", []),
     ("yamd_bneck.hip", []),
+    ("yamd_c3.hip", []),
     ("yamd_microbench.hip", []),
     ("yamd_plan.hip", []),
 ]

@@ -32,6 +32,8 @@ int run_op(const yamd_plan &pl, const yamd_plan_op &o, const float *images, void
                                          p[4], i[2], p[5], i[5], i[6], pl.batch, i[3], i[4], st);
     case YAMD_OP_BOTTLENECK:
         return yamd_bottleneck(i[1], i[5], i[6], i[7], p[0], i[0], p[1], (const float *)p[2], i[8], p[4], i[2], pl.batch, i[3], i[4], st);
+    case YAMD_OP_C3:
+        return yamd_c3_fused(i[1], i[5], i[6], i[7], p[0], i[0], p[1], (const float *)p[2], i[8], p[4], i[2], pl.batch, i[3], i[4], st);
     case YAMD_OP_STEM:
         return yamd_stem_conv(i[0], images, pl.batch, pl.img_h, pl.img_w, p[1], (const float *)p[2], i[1], i[2], p[4], i[3], st);
     case YAMD_OP_STEM_CONV2:
@@ -67,7 +69,7 @@ extern "C" int yamd_plan_create(const yamd_plan_op *ops, int n_ops, int batch, i
     YAMD_REQUIRE(ops && plan_out && n_ops > 0 && n_ops <= 65536, "bad argument (n_ops=%d)", n_ops);
     YAMD_REQUIRE(batch > 0 && img_h > 0 && img_w > 0, "bad shape %dx%dx%d", batch, img_h, img_w);
     for (int k = 0; k < n_ops; ++k)
-        YAMD_REQUIRE(ops[k].kind >= YAMD_OP_CONV && ops[k].kind <= YAMD_OP_BOTTLENECK, "op %d: unknown kind %d", k, ops[k].kind);
+        YAMD_REQUIRE(ops[k].kind >= YAMD_OP_CONV && ops[k].kind <= YAMD_OP_C3, "op %d: unknown kind %d", k, ops[k].kind);
     yamd_plan *pl = new (std::nothrow) yamd_plan;
     YAMD_REQUIRE(pl != nullptr, "out of host memory");
     pl->ops.assign(ops, ops + n_ops);

@@ -34,7 +34,8 @@ class View(NamedTuple):
 FUSE = {"stem": True,          # first conv straight from the fp32 image (yamd_stem_conv)
         "stem_conv2": True,    # stride-2 stem + the 3x3 stride-2 conv after it as one launch (yamd_stem_conv2)
         "upsample_cat": True,  # 1x1 convs read torch.cat((up(a), b), 1) from a and b themselves (yamd_conv2d_bias_act_cat2)
-        "bottleneck": True}    # 1x1 conv + 3x3 conv (+ shortcut) of a narrow residual unit as one launch (yamd_bottleneck)
+        "bottleneck": True,    # 1x1 conv + 3x3 conv (+ shortcut) of a narrow residual unit as one launch (yamd_bottleneck)
+        "c3": True}            # a whole narrow C3 block with one bottleneck as one launch (yamd_c3_fused)
 
 _PACK_GENERATION = [0]      # bumped whenever a layer's packed weights or descriptor change: compiled C plans are stale then
 
@@ -204,6 +205,45 @@ class BottleneckLayer:
         _lib.check(LIB.yamd_bottleneck_pack_weights(cin, cmid, cout, first._w.data_ptr(), b1.data_ptr(), second._w.data_ptr(),
                                                     b2.data_ptr(), self.w_host.data_ptr(), self.b_host.data_ptr()),
                    f"bottleneck_pack_weights[{self.name}]")
+        self.w_dev: Optional[torch.Tensor] = None
+        self.b_dev: Optional[torch.Tensor] = None
+
+    def to(self, device) -> None:
+        if self.w_dev is None or self.w_dev.device != torch.device(device):
+            self.w_dev = self.w_host.to(device)
+            self.b_dev = self.b_host.to(device)
+
+
+class C3Layer:
+    """A whole C3 block with one bottleneck run as one launch (``yamd_c3_fused``): ``entry`` is the 1x1 conv that computes
+    both branches (output channels [cv2 | cv1]), ``unit`` the fused bottleneck on the cv1 branch, ``exit`` the 1x1 conv
+    over [bottleneck output | cv2 branch].  None of the tensors between them is written to memory."""
+
+    def __init__(self, entry: ConvLayer, unit: BottleneckLayer, exit_: ConvLayer):
+        ch = unit.cin
+        cin, cout = entry._w.shape[1], exit_._w.shape[0]
+        self.name = f"{entry.name}+{unit.name}+{exit_.name}"
+        self.entry, self.unit, self.exit = entry, unit, exit_
+        self.cin, self.ch, self.cout, self.act = cin, ch, cout, entry._args[4]
+        self.macs_per_pixel = entry.macs_per_pixel + unit.macs_per_pixel + exit_.macs_per_pixel
+        n = LIB.yamd_c3_packed_elems(cin, ch, cout)
+        if n <= 0:
+            raise _lib.YamdError(f"c3[{self.name}]: {cin} > {ch} > {cout} channels not supported")
+        self.w_host = torch.empty(n, dtype=torch.int16)
+        self.b_host = torch.empty(4 * ch + cout, dtype=torch.float32)
+        zeros = lambda k: torch.zeros(k, dtype=torch.float32)
+        be = entry._b if entry._b is not None else zeros(2 * ch)
+        w_cv2, w_cv1 = entry._w[:ch].contiguous(), entry._w[ch:].contiguous()
+        b_cv2, b_cv1 = be[:ch].contiguous(), be[ch:].contiguous()
+        l1, l2 = unit.first, unit.second
+        b_m1 = l1._b if l1._b is not None else zeros(ch)
+        b_m2 = l2._b if l2._b is not None else zeros(ch)
+        b3 = exit_._b if exit_._b is not None else zeros(cout)
+        self._keep = (w_cv1, w_cv2, b_cv1, b_cv2, b_m1, b_m2, b3)
+        _lib.check(LIB.yamd_c3_pack_weights(cin, ch, cout, w_cv1.data_ptr(), b_cv1.data_ptr(), w_cv2.data_ptr(), b_cv2.data_ptr(),
+                                            l1._w.data_ptr(), b_m1.data_ptr(), l2._w.data_ptr(), b_m2.data_ptr(),
+                                            exit_._w.data_ptr(), b3.data_ptr(), self.w_host.data_ptr(), self.b_host.data_ptr()),
+                   f"c3_pack_weights[{self.name}]")
         self.w_dev: Optional[torch.Tensor] = None
         self.b_dev: Optional[torch.Tensor] = None
 
@@ -505,7 +545,7 @@ class Program:
         buf, coff = self.resolve(v)
         if buf in self.fused_away:
             raise _lib.YamdError(f"activation '{buf}' is not materialised: its layer runs fused with the next one (set "
-                                 "yolo_amd.engine.FUSE['stem_conv2'] / ['bottleneck'] = False before building the model to inspect it)")
+                                 "yolo_amd.engine.FUSE['stem_conv2'] / ['bottleneck'] / ['c3'] = False before building the model to inspect it)")
         if any(b == buf and c0 < coff + v.c and c1 > coff for b, c0, c1 in self.unwritten):
             raise _lib.YamdError(f"activation '{buf}'[{coff}:{coff + v.c}] is not materialised: its readers take the upsampled "
                                  "tensor from the low-resolution one (set yolo_amd.engine.FUSE['upsample_cat'] = False before "
@@ -513,7 +553,7 @@ class Program:
         return bufs[buf][..., coff:coff + v.c].permute(0, 3, 1, 2).float().contiguous()
 
     def n_conv_launches(self) -> int:
-        return sum(1 for op in self.ops if op[0] in ("conv", "conv_cat2", "stem", "stem2", "bneck"))
+        return sum(1 for op in self.ops if op[0] in ("conv", "conv_cat2", "stem", "stem2", "bneck", "c3"))
 
     def conv_launch_signature(self) -> List[str]:
         """One string per conv launch of a pass, in launch order: kind, layer name, shape and tiling.  Two plans with the
@@ -527,6 +567,8 @@ class Program:
                 sig.append(f"{kind} {op[1].name} k{d.ksize}s{d.stride} {d.cin}>{d.cout} @{o.h}x{o.w} tiling={op[1].tiling}")
             elif kind == "bneck":
                 sig.append(f"bneck {op[1].name} {op[1].cin}>{op[1].cmid}>{op[1].cout} @{op[3].h}x{op[3].w}")
+            elif kind == "c3":
+                sig.append(f"c3 {op[1].name} {op[1].cin}>{op[1].ch}>{op[1].cout} @{op[3].h}x{op[3].w}")
             elif kind in ("stem", "stem2"):
                 sig.append(f"{kind} {op[1].name} @{op[2].h}x{op[2].w}")
         return sig
@@ -538,7 +580,7 @@ class Program:
                 total += op[1].macs_per_pixel * op[3].h * op[3].w
             elif op[0] == "conv_cat2":
                 total += op[1].macs_per_pixel * op[6].h * op[6].w
-            elif op[0] == "bneck":      # the MACs of the two layers, not of the fused kernel (which recomputes the halo of the first)
+            elif op[0] in ("bneck", "c3"):      # the MACs of the layers, not of the fused kernel (which recomputes halos)
                 total += op[1].macs_per_pixel * op[3].h * op[3].w
             elif op[0] == "stem":
                 total += op[1].macs_per_pixel * op[2].h * op[2].w
@@ -571,7 +613,7 @@ class Program:
             cout = out.c + (out2.c if out2 is not None else 0)
             byts = batch * (xa.h * xa.w * xa.c + xb.h * xb.w * xb.c) * 2 + px * cout * (4 if layer.desc.out_f32 else 2) + layer.macs_per_pixel * 2
             return 2.0 * layer.macs_per_pixel * px, float(byts)
-        if kind == "bneck":
+        if kind in ("bneck", "c3"):
             _, layer, x, out, _sc = op
             px = batch * out.h * out.w
             return 2.0 * layer.macs_per_pixel * px, float(px * (x.c + out.c) * 2 + layer.macs_per_pixel * 2)
@@ -609,7 +651,7 @@ class Program:
             return [v for v in (op[2], op[4]) if v is not None]
         if kind == "conv_cat2":
             return [op[2], op[4]]
-        if kind == "bneck":
+        if kind in ("bneck", "c3"):
             return [op[2]]
         if kind in ("up2", "copy", "d2s", "mp2", "mp5"):
             return [op[1]]
@@ -704,6 +746,62 @@ class Program:
             fused += 1
         return fused
 
+    def fuse_c3(self) -> int:
+        """Replaces [1x1 conv to two branches, fused bottleneck on one of them, 1x1 conv over (bottleneck output | other
+        branch)] -- a C3 block with one bottleneck after ``fuse_bottlenecks`` -- by one ``c3`` op when the library builds
+        the fused kernel for those widths and nothing else reads the tensors in between.  Returns the number of blocks
+        fused.  Runs once, before the first buffers are allocated."""
+        def rng(v: View):
+            buf, coff = self.resolve(v)
+            return buf, coff, coff + v.c
+
+        def overlaps(a, b):
+            return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
+
+        fused, j = 0, 0
+        while j + 2 < len(self.ops):
+            e, u, x3 = self.ops[j], self.ops[j + 1], self.ops[j + 2]
+            j += 1
+            if e[0] != "conv" or u[0] != "bneck" or x3[0] != "conv":
+                continue
+            _, le, x, b_out, res_e, a_out = e
+            _, lu, u_in, m_out, shortcut = u
+            _, lx, cat_in, y, res_x, y2 = x3
+            if a_out is None or res_e is not None or res_x is not None or y2 is not None:
+                continue
+            ke, se, _cin, _cout, act_e, f_e = le._args
+            kx, sx, _c2, _c3, act_x, f_x = lx._args
+            ch = lu.cin
+            if not (ke == 1 and kx == 1 and se == 1 and sx == 1 and not f_e and not f_x and act_e == act_x == lu.act == _lib.ACT_SILU
+                    and lu.cmid == ch and lu.cout == ch and b_out.c == ch and a_out.c == ch and le.cin_real == x.c
+                    and lx.cin_real == 2 * ch and LIB.yamd_c3_packed_elems(x.c, ch, y.c) > 0
+                    and le.residual_scale == 1.0 and lx.residual_scale == 1.0):
+                continue
+            # the bottleneck reads the cv1 branch, and the exit conv reads exactly [bottleneck output | cv2 branch]
+            ra, rb, rm, rcat = rng(a_out), rng(b_out), rng(m_out), rng(cat_in)
+            if rng(u_in) != ra or rm[0] != rb[0] or rm[2] != rb[1] or rcat != (rm[0], rm[1], rb[2]):
+                continue
+            inner = (ra, rb, rm)
+            if any(overlaps(rng(v), r) for v in self.outputs.values() for r in inner):
+                continue
+            if any(overlaps(rng(v), r) for k, op in enumerate(self.ops) if k not in (j, j + 1) for v in self._inputs_of(op) for r in inner):
+                continue      # (k == j: the bottleneck, k == j + 1: the exit conv)
+            if overlaps(rng(x), rng(y)) or a_out.buf in self.alias or m_out.buf in self.alias:
+                continue
+            if self.buffers[a_out.buf][2] != ch or self.buffers[m_out.buf][2] != 2 * ch:
+                continue
+            layer = C3Layer(le, lu, lx)
+            self.ops[j - 1:j + 2] = [("c3", layer, x, y, shortcut)]
+            self.convs.remove(le)
+            self.convs.remove(lx)
+            self.stems.remove(lu)
+            self.stems.append(layer)
+            for buf in (a_out.buf, m_out.buf):
+                del self.buffers[buf]
+                self.fused_away.add(buf)
+            fused += 1
+        return fused
+
     def _buffers_for(self, batch: int, device) -> Dict[str, torch.Tensor]:
         if not self._finalized:
             self._finalized = True
@@ -711,6 +809,8 @@ class Program:
                 self.fuse_upsample_cat()
             if FUSE["bottleneck"]:
                 self.fuse_bottlenecks()
+                if FUSE["c3"]:
+                    self.fuse_c3()
         key = (batch, str(device))
         if key not in self._alloc:
             self._alloc.clear()   # one live batch size at a time: the arena is large
@@ -780,6 +880,13 @@ class Program:
                 fill(_lib.OP_BOTTLENECK, (xcs, layer.cin, ycs, out.h, out.w, layer.cmid, layer.cout, layer.act, shortcut),
                      {0: xp, 1: layer.w_dev.data_ptr(), 2: layer.b_dev.data_ptr(), 4: yp})
                 names.append(f"bottleneck[{layer.name}]")
+            elif kind == "c3":
+                _, layer, x, out, shortcut = op
+                xp, xcs = P(bufs, x)
+                yp, ycs = P(bufs, out)
+                fill(_lib.OP_C3, (xcs, layer.cin, ycs, out.h, out.w, layer.ch, layer.cout, layer.act, shortcut),
+                     {0: xp, 1: layer.w_dev.data_ptr(), 2: layer.b_dev.data_ptr(), 4: yp})
+                names.append(f"c3[{layer.name}]")
             elif kind == "stem":
                 _, layer, out = op
                 yp, ycs = P(bufs, out)
@@ -851,7 +958,7 @@ class Program:
         for op in self.ops:
             kind = op[0]
             if conv_spans is not None:
-                is_conv = kind in ("conv", "conv_cat2", "stem", "stem2", "bneck")
+                is_conv = kind in ("conv", "conv_cat2", "stem", "stem2", "bneck", "c3")
                 if is_conv and span_open is None:
                     span_open = torch.cuda.Event(enable_timing=True)
                     span_open.record()
@@ -892,6 +999,12 @@ class Program:
                 yp, ycs = P(bufs, out)
                 _lib.check(LIB.yamd_bottleneck(layer.cin, layer.cmid, layer.cout, layer.act, xp, xcs, layer.w_dev.data_ptr(),
                                                layer.b_dev.data_ptr(), shortcut, yp, ycs, B, out.h, out.w, st), f"bottleneck[{layer.name}]")
+            elif kind == "c3":
+                _, layer, x, out, shortcut = op
+                xp, xcs = P(bufs, x)
+                yp, ycs = P(bufs, out)
+                _lib.check(LIB.yamd_c3_fused(layer.cin, layer.ch, layer.cout, layer.act, xp, xcs, layer.w_dev.data_ptr(),
+                                             layer.b_dev.data_ptr(), shortcut, yp, ycs, B, out.h, out.w, st), f"c3[{layer.name}]")
             elif kind == "stem":
                 _, layer, out = op
                 yp, ycs = P(bufs, out)
@@ -943,7 +1056,7 @@ class Program:
             if timings is not None:
                 ev1 = torch.cuda.Event(enable_timing=True)
                 ev1.record()
-                if kind in ("stem", "stem2", "conv_cat2", "bneck"):          # reported with the convs
+                if kind in ("stem", "stem2", "conv_cat2", "bneck", "c3"):          # reported with the convs
                     timings.append(("conv", op[1].name, ev0, ev1) + self.op_cost(op, B))
                 else:
                     timings.append((kind, op[1].name if kind == "conv" else kind, ev0, ev1) + self.op_cost(op, B))

@@ -22,13 +22,14 @@ EXPORTS = [
     "yamd_copy_channels", "yamd_depth_to_space2", "yamd_decode_ltrb_points",
     "yamd_decode_anchor", "yamd_decode_anchor_levels", "yamd_decode_dfl", "yamd_decode_dfl_unit_conf", "yamd_decode_dfl_points", "yamd_nms_workspace_bytes", "yamd_nms_batched", "yamd_nms_static_capacity_bytes", "yamd_nms_batched_static", "yamd_compact_rows", "yamd_letterbox_workspace_bytes", "yamd_letterbox_u8", "yamd_detect_match", "yamd_stem_packed_elems", "yamd_stem_pack_weights", "yamd_stem_conv", "yamd_stem_conv2_packed_elems", "yamd_stem_conv2_pack_weights", "yamd_stem_conv2",
     "yamd_bottleneck_packed_elems", "yamd_bottleneck_pack_weights", "yamd_bottleneck",
+    "yamd_c3_packed_elems", "yamd_c3_pack_weights", "yamd_c3_fused",
     "yamd_microbench_mfma_bf16", "yamd_microbench_copy", "yamd_microbench_clock_probe",
     "yamd_plan_create", "yamd_plan_run", "yamd_plan_size", "yamd_plan_destroy",
 ]
 
 # yamd_plan_op.kind
 OP_CONV, OP_CONV_SPLIT, OP_STEM, OP_STEM_CONV2, OP_FOCUS, OP_NHWC16, OP_UPSAMPLE2X, OP_MAXPOOL5_CASCADE, \
-    OP_MAXPOOL3_CASCADE, OP_MAXPOOL2, OP_DEPTH_TO_SPACE2, OP_COPY_CHANNELS, OP_CONV_CAT2, OP_BOTTLENECK = range(1, 15)
+    OP_MAXPOOL3_CASCADE, OP_MAXPOOL2, OP_DEPTH_TO_SPACE2, OP_COPY_CHANNELS, OP_CONV_CAT2, OP_BOTTLENECK, OP_C3 = range(1, 16)
 
 
 class ConvDesc(ctypes.Structure):
@@ -106,6 +107,10 @@ def _load() -> ctypes.CDLL:
     lib.yamd_bottleneck_pack_weights.argtypes = [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     lib.yamd_bottleneck.argtypes = [c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                     c_int, c_int, c_int, c_void_p]
+    lib.yamd_c3_packed_elems.restype = c_int64
+    lib.yamd_c3_packed_elems.argtypes = [c_int, c_int, c_int]
+    lib.yamd_c3_pack_weights.argtypes = [c_int, c_int, c_int] + [c_void_p] * 12
+    lib.yamd_c3_fused.argtypes = lib.yamd_bottleneck.argtypes
     lib.yamd_microbench_mfma_bf16.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p]
     lib.yamd_microbench_copy.argtypes = [c_void_p, c_void_p, c_size_t, c_int, c_void_p]
     lib.yamd_microbench_clock_probe.argtypes = [c_void_p, c_int, c_int, c_void_p]
@@ -129,7 +134,7 @@ def _load() -> ctypes.CDLL:
     lib.yamd_plan_destroy.restype = None
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("yamd_plan_destroy","yamd_last_error", "yamd_nms_workspace_bytes", "yamd_letterbox_workspace_bytes", "yamd_stem_packed_elems", "yamd_stem_conv2_packed_elems", "yamd_bottleneck_packed_elems",
+        if name not in ("yamd_plan_destroy","yamd_last_error", "yamd_nms_workspace_bytes", "yamd_letterbox_workspace_bytes", "yamd_stem_packed_elems", "yamd_stem_conv2_packed_elems", "yamd_bottleneck_packed_elems", "yamd_c3_packed_elems",
                         "yamd_nms_static_capacity_bytes"):
             fn.restype = c_int
     return lib
