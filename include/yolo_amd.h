@@ -234,6 +234,20 @@ int yamd_nms_batched(const float *pred, int batch, int a, int c, int in_cxcywh, 
                      float conf_thr, double iou_thr, float *out_rows, int *out_index, int max_out,
                      int *out_counts, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The predict path's post-processing as one call: yamd_decode_anchor_levels followed by yamd_nms_batched (in_cxcywh = 1),
+ * i.e. everything `predict` does after `self.body_net(images)` (yolov5/YoloV5.py:108-127 over yolov5/YoloV5Head.py:23-60 and
+ * utils/torch_utils.py:101-141; the pose / face forms :144-241), with the confidence filter run inside the decode kernel
+ * on the rows it has just decoded.  Only rows that pass are written to `pred` (the NMS kernels read them there); the others
+ * are left as they were, so `pred` is scratch of this call, not a result: callers that want the decoded tensor
+ * (`_forward`) use yamd_decode_anchor_levels.  out_rows / out_index / out_counts are those of yamd_nms_batched on the
+ * fully decoded tensor, bit for bit.  n_extra follows from the kind: 3 * point_num (pose), 2 * point_num (face), else 0.
+ * workspace as for yamd_nms_batched with a = na * sum(h * w). */
+int yamd_decode_nms_anchor(int kind, const float *const *raw_host_ptrs, const int *hs_host, const int *ws_host,
+                           const int *strides_host, const float *anchors_wh_host, int n_levels, int batch, int na, int c,
+                           int point_num, float img_size, int clamp_points, float *pred, float conf_thr, double iou_thr,
+                           float *out_rows, int *out_index, int max_out, int *out_counts, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* yamd_nms_batched for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc): the same kernels, with the workspace taken from a static device array of the
  * library instead of a caller buffer, so the call allocates and frees nothing.  No counterpart in the reference.

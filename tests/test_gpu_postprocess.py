@@ -315,3 +315,58 @@ def test_nms_more_oversized_buckets_than_compute_units(gpu_device):
             assert np.array_equal(r[b, :k].view(np.uint32), want[0].view(np.uint32))
             assert np.array_equal(ix[b, :k].astype(np.int64), want_idx[0])
         assert (r[:, :k] == r[0, :k]).all()
+
+
+@pytest.mark.parametrize("kind_name,C,P,sizes,conf,scale,bias", [
+    ("v5", 25, 0, [(16, 24), (8, 12), (4, 6)], 0.1, 2.0, 0.0),        # most anchors pass
+    ("v5", 25, 0, [(80, 80), (40, 40), (20, 20)], 0.1, 1.0, 0.0),     # the benchmark's level sizes
+    ("v5", 25, 0, [(19, 19), (10, 10), (5, 3)], 0.3, 2.0, -3.0),      # few pass; ragged sizes
+    ("v5", 6, 0, [(8, 8), (4, 4), (2, 2)], 0.999, 1.0, -9.0),         # nothing passes anywhere
+    ("v3", 85, 0, [(13, 13), (7, 7), (4, 4)], 0.2, 1.5, -1.0),
+    ("pose", 57, 17, [(12, 20), (6, 10), (3, 5)], 0.3, 2.0, -1.0),
+    ("face", 16, 5, [(16, 16), (8, 8), (4, 4)], 0.3, 2.0, -1.0),
+])
+def test_decode_filter_nms_in_one_call_equals_the_two_steps(gpu_device, kind_name, C, P, sizes, conf, scale, bias):
+    """yamd_decode_nms_anchor (the decode kernel filters its own rows; rows that fail are never written) against
+    yamd_decode_anchor_levels + yamd_nms_batched: counts, rows and kept source indices bit for bit, and against the CPU
+    oracle on the decoded tensor; the rows it did write into the scratch tensor are the decoded ones."""
+    from oracle import postprocess as pp
+    from yolo_amd import lib as L, torch_utils as tu
+    kind = {"v5": L.DECODE_V5, "v3": L.DECODE_V3, "pose": L.DECODE_POSE, "face": L.DECODE_FACE}[kind_name]
+    rng = np.random.RandomState(C * 7 + len(sizes) + sizes[0][0])
+    anchors = [(10, 13), (16, 30), (33, 23), (30, 61), (62, 45), (59, 119), (116, 90), (156, 198), (373, 326)]
+    strides, img = [8, 16, 32], float(sizes[0][0] * 8)
+    B = 3
+    raws_np = []
+    for h, w in sizes:
+        r = (rng.standard_normal((B, 3 * C, h, w)) * scale).astype(np.float32)
+        r[:, 4::C] += bias                                      # objectness logit of every anchor
+        raws_np.append(r)
+    raws_np[0][1] -= 40.0 if bias < 0 else 0.0                  # (one image with no candidate on the finest level)
+    raws = [_nhwc(r, gpu_device) for r in raws_np]
+    n_extra = {"pose": 3 * P, "face": 2 * P}.get(kind_name, 0)
+    clamp = kind_name == "pose"
+    pred = tu.decode_anchor_levels(raws, anchors, strides, img, kind, P, clamp)
+    rows0, counts0, index0 = tu.nms_batched(pred, img, "cxcywh", conf, 0.3, n_extra, want_index=True)
+    arena = tu.Arena()
+    arena.get("decoded", pred.shape, torch.float32, gpu_device).fill_(float("nan"))      # rows that fail must stay untouched
+    rows1, counts1, index1 = tu.decode_nms_anchor_levels(raws, anchors, strides, img, kind, P, clamp, conf, 0.3,
+                                                         want_index=True, arena=arena)
+    torch.cuda.synchronize()
+    assert torch.equal(counts0, counts1)
+    c = counts0.cpu().tolist()
+    for b in range(B):
+        assert torch.equal(rows0[b, :c[b]].view(torch.int32), rows1[b, :c[b]].view(torch.int32))
+        assert torch.equal(index0[b, :c[b]], index1[b, :c[b]])
+    want = pp.non_max_suppression(pred.cpu().numpy(), img, "cxcywh", conf, 0.3, point_num=P, point_conf=kind_name == "pose")
+    _check_rows(rows1, counts1, want)
+    # the scratch tensor: exactly the rows that pass the confidence filter were written, with the decoded values
+    scratch = arena.get("decoded", pred.shape, torch.float32, gpu_device)
+    nc = C - 5 - n_extra
+    passed = (pred[..., 4] * pred[..., 5 + n_extra:].max(-1).values) >= torch.tensor(conf, dtype=torch.float32)
+    assert torch.equal(scratch[passed].view(torch.int32), pred[passed].view(torch.int32))
+    assert torch.isnan(scratch[~passed]).all()
+    if conf > 0.99:
+        assert sum(c) == 0 and not passed.any()
+    else:
+        assert sum(c) > 0 and nc >= 1

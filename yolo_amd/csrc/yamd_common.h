@@ -65,6 +65,23 @@ struct KernelAttr {
     }
 };
 
+// The confidence filter of the NMS front end run inside another kernel (the decode of the predict path filters the rows
+// it has just decoded, while they are in LDS): where its survivors go inside an NMS workspace.
+struct FilterTargets {
+    unsigned *img_count, *cls_count;              // per image / per (image, class) candidate counters, zero at launch
+    unsigned long long *tmp_key, *tmp_meta;       // unordered candidate lists, `a` slots per image
+    int a, nc, n_extra;
+    float conf_thr;
+};
+// yamd_nms.hip: checks the shape, lays out `workspace`, enqueues the clearing of its counters and fills `ft`
+int nms_filter_targets(int batch, int a, int c, int n_extra, float conf_thr, void *workspace, size_t workspace_bytes, void *stream,
+                       FilterTargets *ft);
+// yamd_decode.hip: yamd_decode_anchor_levels that also filters: rows that pass are written to `out` and entered into `ft`'s
+// lists, the others are not written at all.  YAMD_ENOSPC when the class count does not fit the kernel's LDS tile
+int decode_anchor_levels_filtered(int kind, const float *const *raws, const int *hs, const int *ws, const int *strides,
+                                  const float *anchors_wh_host, int n_levels, int batch, int na, int c, int point_num, float img_size,
+                                  int clamp_points, float *out, const FilterTargets &ft, void *stream);
+
 // per-device set-up of the NMS kernels and their static scratch array (yamd_nms.hip), called by yamd_init
 int nms_init_current_device(int device);
 // resolves the address of the fused stem's tile counters on the current device (yamd_stem.hip), called by yamd_init

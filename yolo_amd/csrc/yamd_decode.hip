@@ -10,6 +10,7 @@
 #include "yamd_common.h"
 
 #include <cmath>
+#include <cstring>
 
 using namespace yamd;
 
@@ -80,12 +81,33 @@ struct AnchorDecodeParams {
     unsigned nac_magic;       // the same for na*C
     float hi;                 // img_size - 1
     long long rows_per_image;
+    FilterTargets ft;         // FILTER instantiation only
     Level lv[MAX_LEVELS];
 };
 
+__device__ __forceinline__ unsigned order_bits(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// FILTER: the predict path's form.  Every decoded row is put through the confidence filter of the NMS front end while it
+// is still in LDS (utils/torch_utils.py:128-136: first-maximum class, fp32 product obj * class score >= threshold); rows
+// that pass are entered into the NMS candidate lists (key = score bits and anchor index, ticket inside the (image, class)
+// bucket) and written to `out`, rows that fail are not written: the decoded tensor is neither written nor read back in
+// full.  The values are those of the plain kernel bit for bit (same code), so the lists equal the separate filter's.
+template <bool FILTER>
 __global__ __launch_bounds__(256) void decode_anchor_kernel(AnchorDecodeParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float sraw[];     // pix rows of rstr floats (na*C logits each)
+    unsigned *const hist = (unsigned *)(sraw + p.pix * p.rstr);      // FILTER: nc bucket counts of this workgroup,
+    unsigned *const cbase = hist + p.ft.nc;                          // nc bucket bases,
+    unsigned *const misc = cbase + p.ft.nc;                          // [0] survivors of the workgroup, [1] their base in the image,
+    unsigned char *const sflag = (unsigned char *)(misc + 4);        // one pass flag per row (anchor-major)
+    if constexpr (FILTER) {
+        for (int c = threadIdx.x; c < p.ft.nc; c += 256) hist[c] = 0u;
+        if (threadIdx.x == 0) misc[0] = 0u;
+    }
     int li = 0;
 #pragma unroll
     for (int i = 1; i < MAX_LEVELS; ++i)
@@ -150,6 +172,46 @@ __global__ __launch_bounds__(256) void decode_anchor_kernel(AnchorDecodeParams p
     }
     __syncthreads();
 
+    if constexpr (FILTER) {
+        // one row per thread: row r = (anchor a, pixel) with the pixel varying fastest, as the output orders them
+        const int nrow = p.na * np, tid = threadIdx.x;
+        bool pass = false;
+        unsigned cls = 0u, lt = 0u, lp = 0u;
+        unsigned long long key = 0ull;
+        if (tid < nrow) {
+            const int a = tid / np, pix = tid - a * np;
+            const float *row = sraw + pix * RSTR + a * C;
+            const float *sc = row + 5 + p.ft.n_extra;
+            float best = sc[0];
+            int bi = 0;
+            for (int c = 1; c < p.ft.nc; ++c) {
+                const float v = sc[c];
+                if (v > best) { best = v; bi = c; }
+            }
+            const float score = row[4] * best;
+            if (score >= p.ft.conf_thr) {
+                pass = true;
+                cls = (unsigned)bi;
+                const unsigned idx = (unsigned)(L.row_offset + (long long)a * HW + p0 + pix);      // row inside the image
+                key = ((unsigned long long)order_bits(score) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+                lt = atomicAdd(&hist[cls], 1u);
+                lp = atomicAdd(&misc[0], 1u);
+            }
+            sflag[tid] = pass ? 1 : 0;
+        }
+        __syncthreads();
+        for (int c = tid; c < p.ft.nc; c += 256)
+            if (hist[c]) cbase[c] = atomicAdd(&p.ft.cls_count[b * p.ft.nc + c], hist[c]);
+        if (tid == 0 && misc[0]) misc[1] = atomicAdd(&p.ft.img_count[b], misc[0]);
+        __syncthreads();
+        if (pass) {
+            const long long pos = b * p.ft.a + misc[1] + lp;
+            p.ft.tmp_key[pos] = key;
+            p.ft.tmp_meta[pos] = ((unsigned long long)cls << 32) | (unsigned long long)(cbase[cls] + lt);
+        }
+        if (misc[0] == 0u) return;                                   // nothing of this workgroup's rows survives
+    }
+
     // Phase B: the np rows of one anchor are one contiguous run of np*C floats in the output.
     const int run = np * C;
     for (int a = 0; a < p.na; ++a) {
@@ -157,6 +219,38 @@ __global__ __launch_bounds__(256) void decode_anchor_kernel(AnchorDecodeParams p
                                             : (b * p.na + a) * (long long)HW + p0;
         float *dst = p.out + first_row * C;
         const float *sa = sraw + a * C;
+        if constexpr (FILTER) {
+            // as store_run, but only the elements of rows that passed are stored (16 bytes at once where four
+            // consecutive elements all belong to such rows)
+            const unsigned char *fl = sflag + a * np;
+            const bool vec = ((uintptr_t)dst & 15) == 0;
+            const int n4 = vec ? (run >> 2) : 0;
+            for (int q = threadIdx.x; q < n4; q += 256) {
+                const int e = 4 * q;
+                int pix = (int)(((unsigned)e * p.c_magic) >> 22), c = e - pix * C;
+                float v[4];
+                unsigned ok = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = sa[pix * RSTR + c];
+                    ok |= (unsigned)fl[pix] << j;
+                    if (++c == C) { c = 0; pix = min(pix + 1, np - 1); }
+                }
+                if (ok == 15u) {
+                    const f32x4 vv = {v[0], v[1], v[2], v[3]};
+                    *((f32x4 *)dst + q) = vv;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((ok >> j) & 1u) dst[e + j] = v[j];
+                }
+            }
+            for (int e = (n4 << 2) + threadIdx.x; e < run; e += 256) {
+                const int pix = (int)(((unsigned)e * p.c_magic) >> 22), c = e - pix * C;
+                if (fl[pix]) dst[e] = sa[pix * RSTR + c];
+            }
+            continue;
+        }
         store_run(dst, run, [&](int e, float &v0, float &v1, float &v2, float &v3) {
             int pix = (int)(((unsigned)e * p.c_magic) >> 22);      // e / C
             int c = e - pix * C;
@@ -332,7 +426,8 @@ int fill_levels(Level *lv, const float *const *raws, const int *hs, const int *w
 
 int decode_anchor_impl(int kind, const float *const *raws, const int *hs, const int *ws, const int *strides,
                        const float *anchors_wh_host, int n_levels, int batch, int na, int c, int point_num, float img_size,
-                       int merge, int clamp_points, float *out, long long rows_per_image, long long row_offset, void *stream)
+                       int merge, int clamp_points, float *out, long long rows_per_image, long long row_offset, void *stream,
+                       const FilterTargets *ft = nullptr)
 {
     YAMD_REQUIRE(raws && hs && ws && strides && out && anchors_wh_host, "null argument");
     YAMD_REQUIRE(kind >= YAMD_DECODE_V5 && kind <= YAMD_DECODE_FACE, "unknown decode kind %d", kind);
@@ -349,7 +444,17 @@ int decode_anchor_impl(int kind, const float *const *raws, const int *hs, const 
     p.nchunk = 1;
     while (p.nchunk < 8 && p.nchunk * na * p.pix < 768 && c / (p.nchunk * 2) >= 4) p.nchunk *= 2;
     p.cw = (c + p.nchunk - 1) / p.nchunk;
-    const size_t lds = (size_t)p.pix * p.rstr * sizeof(float);
+    size_t lds = (size_t)p.pix * p.rstr * sizeof(float);
+    memset(&p.ft, 0, sizeof(p.ft));
+    if (ft) {
+        YAMD_REQUIRE(merge && ft->nc > 0 && ft->nc == c - 5 - ft->n_extra && na * p.pix <= 256, "filter targets do not match the rows");
+        lds += (size_t)(2 * ft->nc + 4) * sizeof(unsigned) + 256;
+        if (lds > 64 * 1024) {
+            set_error("%d classes do not fit the fused decode + filter tile", ft->nc);
+            return YAMD_ENOSPC;
+        }
+        p.ft = *ft;
+    }
     YAMD_REQUIRE(lds <= 64 * 1024 && (long long)(p.pix * c + 4) * c < (1ll << 22) &&
                      (long long)(p.pix * na * c) * (na * c) < (1ll << 22),
                  "na*c=%d too large for the decode tile", na * c);
@@ -381,7 +486,12 @@ int decode_anchor_impl(int kind, const float *const *raws, const int *hs, const 
         YAMD_REQUIRE(n_levels == 1, "the head-module form takes one level");
         p.rows_per_image = rows;
     }
-    hipLaunchKernelGGL(decode_anchor_kernel, dim3(blocks, batch), dim3(256), lds, (hipStream_t)stream, p);
+    if (ft) {
+        YAMD_REQUIRE(rows == ft->a, "filter targets sized for %d rows per image, the levels hold %lld", ft->a, rows);
+        hipLaunchKernelGGL(decode_anchor_kernel<true>, dim3(blocks, batch), dim3(256), lds, (hipStream_t)stream, p);
+    } else {
+        hipLaunchKernelGGL(decode_anchor_kernel<false>, dim3(blocks, batch), dim3(256), lds, (hipStream_t)stream, p);
+    }
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
 }
@@ -445,6 +555,19 @@ extern "C" int yamd_decode_anchor_levels(int kind, const float *const *raw_host_
     return decode_anchor_impl(kind, raw_host_ptrs, hs_host, ws_host, strides_host, anchors_wh_host, n_levels, batch, na, c,
                               point_num, img_size, 1, clamp_points, out, rows, 0, stream);
 }
+
+namespace yamd {
+int decode_anchor_levels_filtered(int kind, const float *const *raws, const int *hs, const int *ws, const int *strides,
+                                  const float *anchors_wh_host, int n_levels, int batch, int na, int c, int point_num, float img_size,
+                                  int clamp_points, float *out, const FilterTargets &ft, void *stream)
+{
+    YAMD_REQUIRE(hs && ws && n_levels > 0 && n_levels <= MAX_LEVELS && na > 0, "bad shape");
+    long long rows = 0;
+    for (int i = 0; i < n_levels; ++i) rows += (long long)na * hs[i] * ws[i];
+    return decode_anchor_impl(kind, raws, hs, ws, strides, anchors_wh_host, n_levels, batch, na, c, point_num, img_size, 1,
+                              clamp_points, out, rows, 0, stream, &ft);
+}
+}  // namespace yamd
 
 extern "C" int yamd_decode_dfl(const float *const *raw_host_ptrs, const int *hs, const int *ws, const int *strides,
                                int n_levels, int batch, int reg_max, int nc, int out_cxcywh, float *out, void *stream)

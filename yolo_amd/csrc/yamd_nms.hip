@@ -1022,7 +1022,7 @@ int scratch_for_current_device(void **out)
 
 int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, int n_extra, float img_size, float conf_thr,
                      double iou_thr, float *out_rows, int *out_index, int max_out, int *out_counts, void *workspace,
-                     size_t workspace_bytes, void *stream);
+                     size_t workspace_bytes, void *stream, bool prefiltered = false);
 }  // namespace
 
 namespace yamd {
@@ -1070,10 +1070,71 @@ extern "C" int yamd_nms_batched_static(const float *pred, int batch, int a, int 
                             out_counts, ptr, YAMD_NMS_STATIC_BYTES, stream);
 }
 
+namespace yamd {
+int nms_filter_targets(int batch, int a, int c, int n_extra, float conf_thr, void *workspace, size_t workspace_bytes, void *stream,
+                       FilterTargets *ft)
+{
+    YAMD_REQUIRE(workspace && ft, "null argument");
+    const int nc = c - 5 - n_extra;
+    YAMD_REQUIRE(batch > 0 && a > 0 && n_extra >= 0 && nc > 0 && nc <= 65535 && batch <= 65535, "bad shape B=%d A=%d C=%d extra=%d", batch, a,
+                 c, n_extra);
+    YAMD_REQUIRE(((uintptr_t)workspace % 256) == 0, "workspace must be 256-byte aligned");
+    const WsLayout L = ws_layout(batch, a, nc);
+    if (workspace_bytes < L.total) {
+        set_error("workspace too small: %zu < %zu", workspace_bytes, L.total);
+        return YAMD_ENOSPC;
+    }
+    char *ws = (char *)workspace;
+    const int pieces = (int)(L.counters_bytes / 16);
+    hipLaunchKernelGGL(nms_clear_kernel, dim3(ceil_div(pieces, 256)), dim3(256), 0, (hipStream_t)stream, (uint4 *)(ws + L.counters), pieces);
+    YAMD_LAUNCH_CHECK();
+    ft->img_count = (u32 *)(ws + L.img_count);
+    ft->cls_count = (u32 *)(ws + L.cls_count);
+    ft->tmp_key = (u64 *)(ws + L.tmp_key);
+    ft->tmp_meta = (u64 *)(ws + L.tmp_meta);
+    ft->a = a;
+    ft->nc = nc;
+    ft->n_extra = n_extra;
+    ft->conf_thr = conf_thr;
+    return YAMD_OK;
+}
+}  // namespace yamd
+
+extern "C" int yamd_decode_nms_anchor(int kind, const float *const *raw_host_ptrs, const int *hs_host, const int *ws_host,
+                                      const int *strides_host, const float *anchors_wh_host, int n_levels, int batch, int na, int c,
+                                      int point_num, float img_size, int clamp_points, float *pred, float conf_thr, double iou_thr,
+                                      float *out_rows, int *out_index, int max_out, int *out_counts, void *workspace,
+                                      size_t workspace_bytes, void *stream)
+{
+    YAMD_REQUIRE(hs_host && ws_host && pred && n_levels > 0 && n_levels <= 8 && na > 0, "bad argument");
+    YAMD_REQUIRE(kind >= YAMD_DECODE_V5 && kind <= YAMD_DECODE_FACE && point_num >= 0, "unknown decode kind %d", kind);
+    long long rows = 0;
+    for (int i = 0; i < n_levels; ++i) rows += (long long)na * hs_host[i] * ws_host[i];
+    YAMD_REQUIRE(rows > 0 && rows < (1ll << 31), "bad level sizes");
+    const int a = (int)rows;
+    const int n_extra = kind == YAMD_DECODE_POSE ? 3 * point_num : (kind == YAMD_DECODE_FACE ? 2 * point_num : 0);
+    FilterTargets ft;
+    int rc = nms_filter_targets(batch, a, c, n_extra, conf_thr, workspace, workspace_bytes, stream, &ft);
+    if (rc != YAMD_OK) return rc;
+    rc = decode_anchor_levels_filtered(kind, raw_host_ptrs, hs_host, ws_host, strides_host, anchors_wh_host, n_levels, batch, na, c,
+                                       point_num, img_size, clamp_points, pred, ft, stream);
+    if (rc == YAMD_ENOSPC) {
+        // more classes than the fused tile holds: the two steps one after the other (the same result)
+        rc = yamd_decode_anchor_levels(kind, raw_host_ptrs, hs_host, ws_host, strides_host, anchors_wh_host, n_levels, batch, na, c,
+                                       point_num, img_size, clamp_points, pred, stream);
+        if (rc != YAMD_OK) return rc;
+        return nms_batched_impl(pred, batch, a, c, 1, n_extra, img_size, conf_thr, iou_thr, out_rows, out_index, max_out, out_counts,
+                                workspace, workspace_bytes, stream);
+    }
+    if (rc != YAMD_OK) return rc;
+    return nms_batched_impl(pred, batch, a, c, 1, n_extra, img_size, conf_thr, iou_thr, out_rows, out_index, max_out, out_counts,
+                            workspace, workspace_bytes, stream, true);
+}
+
 namespace {
 int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, int n_extra, float img_size, float conf_thr,
                      double iou_thr, float *out_rows, int *out_index, int max_out, int *out_counts, void *workspace,
-                     size_t workspace_bytes, void *stream)
+                     size_t workspace_bytes, void *stream, bool prefiltered)
 {
     YAMD_REQUIRE(pred && out_rows && out_counts && workspace, "null argument");
     const int nc = c - 5 - n_extra;
@@ -1171,16 +1232,16 @@ int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, 
         if (rc == YAMD_OK) rc = KernelAttr<&nms_gather_sort_kernel, 150 * 1024>::ensure();
         if (rc != YAMD_OK) return rc;
     }
-    // the counters are cleared by a kernel, not a memset, so that a captured step consists of kernel nodes only
-    {
+    const int achunks = ceil_div(a, 256);
+    p.frows = frows;
+    if (!prefiltered) {      // (prefiltered: the kernel that produced `pred` has filled the counters and candidate lists)
+        // the counters are cleared by a kernel, not a memset, so that a captured step consists of kernel nodes only
         const int pieces = (int)(L.counters_bytes / 16);
         hipLaunchKernelGGL(nms_clear_kernel, dim3(ceil_div(pieces, 256)), dim3(256), 0, st, (uint4 *)(ws + L.counters), pieces);
         YAMD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(nms_filter_kernel, dim3(ceil_div(a, frows), batch), dim3(256), flds, st, p);
+        YAMD_LAUNCH_CHECK();
     }
-    const int achunks = ceil_div(a, 256);
-    p.frows = frows;
-    hipLaunchKernelGGL(nms_filter_kernel, dim3(ceil_div(a, frows), batch), dim3(256), flds, st, p);
-    YAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(64), 0, st, p);
     YAMD_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_bucket_kernel, dim3(achunks, batch), dim3(256), 0, st, p);

@@ -187,9 +187,20 @@ class AnchorTaskModel(TaskModel):
                                                   self.param.nms_threshold, self._n_extra(), arena=arena)
         return rows, counts
 
+    def decode_nms_predict(self, raws, arena=None):
+        """``nms_predict(decode_predict(raws))`` with the confidence filter inside the decode kernel: same rows and counts."""
+        clamp = self.POINT_CONF if self.CLAMP_POINTS_IN_PREDICT is None else self.CLAMP_POINTS_IN_PREDICT
+        rows, counts, _ = torch_utils.decode_nms_anchor_levels(raws, self.param.anchors, self.param.strides, self.param.img_size,
+                                                               self.DECODE_KIND, self.POINT_NUM, self.POINT_NUM > 0 and clamp,
+                                                               self.param.conf_threshold, self.param.nms_threshold, arena=arena)
+        return rows, counts
+
+    def predict_device(self, images: torch.Tensor):
+        return self.decode_nms_predict(self.raw_heads(images), self._arena)
+
     def predict(self, tensor_dict: Dict[str, Any]) -> Dict[str, Any]:
         """Adds ``predicts``: per image ``None`` or ndarray (K, W) in the reference's row layout."""
         tensor_dict = self._feed_forward(tensor_dict)
-        rows, counts = self.nms_predict(self.decode_predict(tensor_dict.pop("_raw_heads")))
+        rows, counts = self.decode_nms_predict(tensor_dict.pop("_raw_heads"))
         tensor_dict["predicts"] = torch_utils.rows_to_host(rows, counts)     # one packed D2H for the batch
         return tensor_dict

@@ -20,7 +20,7 @@ EXPORTS = [
     "yamd_last_error", "yamd_version", "yamd_init", "yamd_conv_desc_init", "yamd_conv_desc_tune", "yamd_conv_pack_weights", "yamd_conv2d_bias_act", "yamd_conv2d_bias_act_split", "yamd_conv2d_bias_act_cat2",
     "yamd_focus_pack", "yamd_nchw_to_nhwc16", "yamd_upsample2x", "yamd_maxpool2", "yamd_maxpool5_cascade", "yamd_maxpool3_cascade",
     "yamd_copy_channels", "yamd_depth_to_space2", "yamd_decode_ltrb_points",
-    "yamd_decode_anchor", "yamd_decode_anchor_levels", "yamd_decode_dfl", "yamd_decode_dfl_unit_conf", "yamd_decode_dfl_points", "yamd_nms_workspace_bytes", "yamd_nms_batched", "yamd_nms_static_capacity_bytes", "yamd_nms_batched_static", "yamd_compact_rows", "yamd_letterbox_workspace_bytes", "yamd_letterbox_u8", "yamd_detect_match", "yamd_stem_packed_elems", "yamd_stem_pack_weights", "yamd_stem_conv", "yamd_stem_conv2_packed_elems", "yamd_stem_conv2_pack_weights", "yamd_stem_conv2",
+    "yamd_decode_anchor", "yamd_decode_anchor_levels", "yamd_decode_dfl", "yamd_decode_dfl_unit_conf", "yamd_decode_dfl_points", "yamd_nms_workspace_bytes", "yamd_nms_batched", "yamd_decode_nms_anchor", "yamd_nms_static_capacity_bytes", "yamd_nms_batched_static", "yamd_compact_rows", "yamd_letterbox_workspace_bytes", "yamd_letterbox_u8", "yamd_detect_match", "yamd_stem_packed_elems", "yamd_stem_pack_weights", "yamd_stem_conv", "yamd_stem_conv2_packed_elems", "yamd_stem_conv2_pack_weights", "yamd_stem_conv2",
     "yamd_bottleneck_packed_elems", "yamd_bottleneck_pack_weights", "yamd_bottleneck",
     "yamd_c3_packed_elems", "yamd_c3_pack_weights", "yamd_c3_fused",
     "yamd_microbench_mfma_bf16", "yamd_microbench_copy", "yamd_microbench_clock_probe",
@@ -122,6 +122,9 @@ def _load() -> ctypes.CDLL:
     lib.yamd_nms_workspace_bytes.argtypes = [c_int, c_int, c_int, c_int]
     lib.yamd_nms_batched.argtypes = [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_double, c_void_p,
                                      c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.yamd_decode_nms_anchor.argtypes = [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                           c_float, c_int, c_void_p, c_float, c_double, c_void_p, c_void_p, c_int, c_void_p,
+                                           c_void_p, c_size_t, c_void_p]
     lib.yamd_compact_rows.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.yamd_nms_static_capacity_bytes.restype = c_size_t
     lib.yamd_nms_static_capacity_bytes.argtypes = []

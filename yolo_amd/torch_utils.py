@@ -153,6 +153,42 @@ def decode_anchor_levels(raws: List[torch.Tensor], anchors, strides, img_size: i
     return out
 
 
+def decode_nms_anchor_levels(raws: List[torch.Tensor], anchors, strides, img_size: int, kind: int, point_num: int,
+                             clamp_points: bool, conf_threshold: float, nms_threshold: float, want_index: bool = False,
+                             arena: Optional[Arena] = None) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+    """``nms_batched(decode_anchor_levels(raws, ...), img_size, "cxcywh", ...)`` as one library call in which the decode
+    kernel filters its own rows (``yamd_decode_nms_anchor``): the same rows, counts and indices bit for bit, without
+    writing and re-reading the full decoded tensor.  The predict path's form; ``_forward`` keeps the plain decode."""
+    B = raws[0].shape[0]
+    n = len(raws)
+    na = len(anchors) // n
+    C = raws[0].shape[-1] // na
+    A = sum(na * r.shape[1] * r.shape[2] for r in raws)
+    dev = raws[0].device
+    for r in raws:
+        _lib.require_gpu(r, torch.float32, "raw head")
+    n_extra = {_lib.DECODE_POSE: 3 * point_num, _lib.DECODE_FACE: 2 * point_num}.get(kind, 0)
+    pred = _out(arena, "decoded", (B, A, C), torch.float32, dev)
+    rows = _out(arena, "nms_rows", (B, A, 7 + n_extra), torch.float32, dev)
+    counts = _out(arena, "nms_counts", (B,), torch.int32, dev)
+    index = _out(arena, "nms_index", (B, A), torch.int32, dev) if want_index else None
+    nbytes = LIB.yamd_nms_workspace_bytes(B, A, C, n_extra)
+    if nbytes == 0:
+        raise _lib.YamdError(f"bad NMS shape B={B} A={A} C={C} extra={n_extra}")
+    ws = _workspace(nbytes, dev) if arena is None else arena.get("nms_workspace", (nbytes,), torch.uint8, dev)
+    ptrs = (ctypes.c_void_p * n)(*[r.data_ptr() for r in raws])
+    hs = (ctypes.c_int * n)(*[r.shape[1] for r in raws])
+    wsz = (ctypes.c_int * n)(*[r.shape[2] for r in raws])
+    ss = (ctypes.c_int * n)(*[int(s_) for s_ in strides])
+    wh = (ctypes.c_float * (2 * na * n))(*[float(v) for a in anchors[:n * na] for v in a])
+    conf32 = float(torch.tensor(conf_threshold, dtype=torch.float32))
+    _lib.check(LIB.yamd_decode_nms_anchor(kind, ptrs, hs, wsz, ss, wh, n, B, na, C, point_num, float(img_size), int(clamp_points),
+                                          pred.data_ptr(), conf32, float(nms_threshold), rows.data_ptr(),
+                                          None if index is None else index.data_ptr(), A, counts.data_ptr(), ws.data_ptr(),
+                                          ws.numel(), _lib.current_stream()), "decode_nms_anchor")
+    return rows, counts, index
+
+
 def decode_anchor_head(raw: torch.Tensor, anchors, stride: int, kind: int, point_num: int = 0) -> torch.Tensor:
     """One head module's output: (B, na, h, w, C) in grid units (e.g. yolov5/YoloV5Head.py:23-60)."""
     _lib.require_gpu(raw, torch.float32, "raw head")
