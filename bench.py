@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the second NMS regime and the peak microbenchmarks (profiling runs: every launch of the "
                          "process then belongs to a full-batch step)")
+    ap.add_argument("--realistic", action="store_true", help="with --no-extras: still time the second NMS regime")
     ap.add_argument("--two-stream", action="store_true", help="NMS of step i on a second stream under step i+1's convs")
     ap.add_argument("--detail", default="", help="write the per-op timing table to this file")
     ap.add_argument("--backend", default="gloo", choices=["gloo", "nccl"],
@@ -697,6 +698,8 @@ def main():
             if world == 1:
                 del images, sink
                 out["latency_small_batch"] = small_batch_latency(model, p, dev)
+        if args.no_extras and args.realistic and world == 1:
+            out["nms_regime_realistic"] = realistic_regime(args, p, model, images, sink)
         if args.detail:
             with open(args.detail, "w") as f:
                 for r in sorted(prof["table"], key=lambda r: -r["ms"]):

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np
 import torch
 from conftest import load_golden
-from test_gpu_models import NAMES, EXP_WH, POINTS, _model, _row_stride
+from test_gpu_models import NAMES, POINTS, _model, _row_stride
 from test_gpu_v5_e2e import _rel_l2
 from oracle import graphs_ref
 from yolo_amd.init import seeded_images

@@ -1,11 +1,15 @@
 """End to end on the GPU for every model family and variant other than YOLOv5 detect (see test_gpu_v5_e2e.py): bf16 conv graph ->
 fp32 decode -> NMS, against the reference's golden outputs (small size) and the CPU oracle graph (full size).
 
-bf16 tolerances (weights and activations rounded to bf16 through the whole conv chain, fp32 accumulate):
-  raw head logits   relative L2 <= 3e-2 vs the fp32 reference
-  decoded boxes     |d| <= 0.5 px + 1 % for all but 0.2 % of the values; scores |d| <= 2e-2 likewise
-                    (v3/v4 width/height: 0.5 px + 5 %, they are exp(logit) * anchor; v6 face and v5 face / pose:
-                    + 4 % of the row's stride resp. anchor size, see _row_stride)
+bf16 tolerances (weights and activations rounded to bf16 through the whole conv chain, fp32 accumulate), as measured with
+scratch/tolerance_probe.py on all 23 models (profiles/r3_tolerance_probe.txt) plus a margin:
+  raw head logits   relative L2 <= 1e-2 vs the fp32 reference (measured <= 4.3e-3); the RepVGG / v6 family <= 1.5e-2
+                    (measured <= 1.02e-2: forty re-parameterised blocks in a row, three summed branches each)
+  decoded boxes     |d| <= 0.5 px + 1 % for all but 0.2 % of the values, keypoints / landmarks the same, for EVERY family,
+                    v3 / v4 widths and heights (exp(logit) x anchor) and the face / pose heads included; the anchor-free
+                    v6 heads get + 3 % of the row's stride (their random-init boxes have sizes near zero, so a relative
+                    allowance means nothing; measured need <= 2.7 % of a cell)
+  scores            |d| <= 1e-2 likewise (measured <= 7.7e-3); v6 family 2e-2 (measured <= 1.6e-2)
 The kept set is compared by matching (same class, IoU > 0.9), because bf16 noise legitimately flips
 threshold decisions; NMS itself is bit-exact given identical input (test_gpu_postprocess.py).
 """
@@ -21,23 +25,25 @@ from test_gpu_v5_e2e import _check_pred, _match_rows, _rel_l2
 pytestmark = pytest.mark.gpu
 
 NAMES = ["v8s", "v3", "v4", "v7pose", "v6face", "v5face", "v5pose", "v7", "v7face", "v6", "v6pose", "v5m", "v8m", "v8n", "v6facen", "v6m", "v6l", "v6facem", "v6posel", "v7x", "v5facem", "v5posex"]
-EXP_WH = ("v3", "v4")
 POINTS = {"v7pose": 17, "v6face": 5, "v5face": 5, "v5pose": 17, "v7face": 5, "v6pose": 17, "v6facen": 5, "v6facem": 5, "v6posel": 17, "v5facem": 5, "v5posex": 17}
 
 
+V6_FAMILY = ("v6face", "v6", "v6pose", "v6facen", "v6m", "v6l", "v6facem", "v6posel")
+
+
 def _row_stride(name, p, size):
-    """per-row length scale (pixels) by which the head multiplies a raw logit: the stride for the anchor-free v6 head,
-    the larger anchor side for the v5 face / pose heads (anchors up to 433 px; landmarks are logit x anchor, sizes
-    (2 sigmoid)^2 x anchor), whose random-init graph reaches the heads with a logit error of a few 1e-2"""
-    if name in ("v6face", "v6", "v6pose", "v6facen", "v6m", "v6l", "v6facem", "v6posel"):
+    """per-row stride (pixels) for the anchor-free v6 heads, whose box columns are (raw logit) x stride; None elsewhere"""
+    if name in V6_FAMILY:
         return np.concatenate([np.full((size // s) ** 2, s, np.float32) for s in p.strides])
-    if name in ("v5face", "v5pose", "v7face", "v5facem", "v5posex"):
-        out = []
-        for lvl, s in enumerate(p.strides):
-            for aw, ah in p.anchors[3 * lvl:3 * lvl + 3]:
-                out.append(np.full((size // s) ** 2, max(aw, ah), np.float32))
-        return np.concatenate(out)
     return None
+
+
+def _raw_tol(name):
+    return 1.5e-2 if name in V6_FAMILY else 1e-2
+
+
+def _score_tol(name):
+    return 2e-2 if name in V6_FAMILY else 1e-2
 
 
 def _match_rows_abs(got, want, tol):
@@ -70,10 +76,10 @@ def test_small_vs_reference_golden(name, gpu_device):
     raws = [r.cpu().numpy().transpose(0, 3, 1, 2) for r in m.raw_heads(imgs)]
     for i, got in enumerate(raws):
         assert got.shape == g[f"raw{i}"].shape
-        assert _rel_l2(got, g[f"raw{i}"]) <= 3e-2, (i, _rel_l2(got, g[f"raw{i}"]))
+        assert _rel_l2(got, g[f"raw{i}"]) <= _raw_tol(name), (i, _rel_l2(got, g[f"raw{i}"]))
     pred = m._forward(imgs)[0].cpu().numpy()
     assert pred.shape == g["pred"].shape
-    _check_pred(pred, g["pred"], size, name in EXP_WH, POINTS.get(name, 0), _row_stride(name, p, size))
+    _check_pred(pred, g["pred"], size, POINTS.get(name, 0), _row_stride(name, p, size), _score_tol(name))
     out = m.predict({"batch_images": imgs})["predicts"]
     want = split_rows(g["counts"], g["rows"])
     for a, b in zip(out, want):
@@ -84,7 +90,7 @@ def test_small_vs_reference_golden(name, gpu_device):
         assert abs(a.shape[0] - b.shape[0]) <= max(3, 0.03 * b.shape[0])
         # measured: 0.976 .. 1.0 for every model except v6m, whose 11 reference rows leave one unmatched (0.909)
         floor = 0.9 if name == "v6m" else 0.95
-        if name in ("v6face", "v6", "v6pose", "v6facen", "v6m", "v6l", "v6facem", "v6posel"):
+        if name in V6_FAMILY:
             assert _match_rows_abs(a, b, 3.0) >= floor
         else:
             assert _match_rows(a, b) >= floor
@@ -107,12 +113,12 @@ def test_full_size_vs_oracle_graph(name, gpu_device):
     with torch.no_grad():
         want_raws = [t.numpy() for t in ref["body"](sd, torch.from_numpy(imgs_np))]
     for i, (got, want) in enumerate(zip(raws, want_raws)):
-        assert _rel_l2(got, want) <= 3e-2, (i, _rel_l2(got, want))
+        assert _rel_l2(got, want) <= _raw_tol(name), (i, _rel_l2(got, want))
     pred = m._forward(imgs)[0].cpu().numpy()
-    _check_pred(pred, ref["decode"](want_raws, p, False), size, name in EXP_WH, POINTS.get(name, 0), _row_stride(name, p, size))
+    _check_pred(pred, ref["decode"](want_raws, p, False), size, POINTS.get(name, 0), _row_stride(name, p, size), _score_tol(name))
     rs = _row_stride(name, p, size)
-    _check_pred(pred[:1, g["pred_rows"]], g["pred"], size, name in EXP_WH, POINTS.get(name, 0),
-                None if rs is None else rs[g["pred_rows"]])
+    _check_pred(pred[:1, g["pred_rows"]], g["pred"], size, POINTS.get(name, 0),
+                None if rs is None else rs[g["pred_rows"]], _score_tol(name))
 
 
 def test_v8_feed_forward_keys(gpu_device):

@@ -2,8 +2,8 @@
 golden outputs and the CPU oracle.
 
 bf16 tolerances (weights and activations rounded to bf16 in 62 chained convs, fp32 accumulate):
-  raw head logits   relative L2 <= 3e-2 vs the fp32 reference
-  decoded boxes     |d| <= 0.5 px + 1 % ; scores |d| <= 2e-2
+  raw head logits   relative L2 <= 1e-2 vs the fp32 reference (measured 9e-4)
+  decoded boxes     |d| <= 0.5 px + 1 % ; scores |d| <= 1e-2
 NMS itself is bit-exact given identical input (tests/test_gpu_postprocess.py); end to end the
 kept set is compared by matching, because bf16 noise legitimately flips threshold decisions.
 """
@@ -30,24 +30,23 @@ def _rel_l2(a, b):
     return float(np.linalg.norm((a - b).astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
 
 
-def _check_pred(got, want, img, exp_wh=False, point_num=0, row_stride=None):
-    """row_stride: per-row stride for anchor-free heads whose box and landmark columns are (raw logit) x stride:
-    the bf16 error of the logit (a few 1e-2 grid cells) scales with the stride, so 4 % of a cell is added."""
-    box_tol = 0.5 + 0.01 * np.abs(want[..., :4])
-    extra = 0.0 if row_stride is None else 0.04 * np.asarray(row_stride, np.float32)[None, :, None]
-    box_tol = box_tol + extra
-    if exp_wh:   # v3/v4: w,h = exp(t)*anchor turns the absolute bf16 error of the logit t into a relative size error
-        box_tol[..., 2:4] = 0.5 + 0.05 * np.abs(want[..., 2:4])
+def _check_pred(got, want, img, point_num=0, row_stride=None, score_tol=1e-2):
+    """Decoded tensor against the fp32 reference: boxes (and keypoints) within 0.5 px + 1 %, scores within ``score_tol``,
+    for all but 0.2 % of the values.  row_stride: per-row stride of the anchor-free v6 heads, whose box columns are (raw
+    logit) x stride with box sizes near zero at random init (a relative allowance means nothing there): 3 % of a grid cell
+    is added (measured need: at most 2.7 %, scratch/tolerance_probe.py)."""
+    extra = 0.0 if row_stride is None else 0.03 * np.asarray(row_stride, np.float32)[None, :, None]
+    box_tol = 0.5 + 0.01 * np.abs(want[..., :4]) + extra
     bad = np.abs(got[..., :4] - want[..., :4]) > box_tol
     assert bad.mean() < 2e-3, f"box mismatch fraction {bad.mean()}"
     if point_num:   # keypoint / landmark coordinates (pixels) sit between obj and the confidences: box tolerance
         k0, k1 = 5, 5 + 2 * point_num
-        badp = np.abs(got[..., k0:k1] - want[..., k0:k1]) > 0.5 + 0.01 * np.abs(want[..., k0:k1]) + extra
+        badp = np.abs(got[..., k0:k1] - want[..., k0:k1]) > 0.5 + 0.01 * np.abs(want[..., k0:k1])
         assert badp.mean() < 2e-3, f"keypoint mismatch fraction {badp.mean()}"
         got = np.concatenate((got[..., :k0], got[..., k1:]), -1)
         want = np.concatenate((want[..., :k0], want[..., k1:]), -1)
     ds = np.abs(got[..., 4:] - want[..., 4:])
-    assert (ds > 2e-2).mean() < 2e-3, f"score mismatch fraction {(ds > 2e-2).mean()}, max {ds.max()}"
+    assert (ds > score_tol).mean() < 2e-3, f"score mismatch fraction {(ds > score_tol).mean()}, max {ds.max()}"
 
 
 def _match_rows(got, want, iou_thr=0.9):
@@ -75,7 +74,7 @@ def test_v5s_64_vs_reference_golden(gpu_device):
     imgs = torch.from_numpy(seeded_images(int(g["batch"]), 64, seed=int(g["seed"]))).to(gpu_device)
     raws = [r.cpu().numpy().transpose(0, 3, 1, 2) for r in m.raw_heads(imgs)]
     for got, key in zip(raws, ("raw_p3", "raw_p4", "raw_p5")):
-        assert _rel_l2(got, g[key]) <= 3e-2, (key, _rel_l2(got, g[key]))
+        assert _rel_l2(got, g[key]) <= 1e-2, (key, _rel_l2(got, g[key]))
     pred = m._forward(imgs)[0].cpu().numpy()
     _check_pred(pred, g["pred"], 64)
     td = m.forward({"batch_images": imgs})
@@ -114,7 +113,7 @@ def test_v5s_640_vs_oracle_graph(gpu_device):
     with torch.no_grad():
         want_raws = [t.numpy() for t in v5_ref.body_forward(sd, torch.from_numpy(imgs_np))]
     for got, want, name in zip(raws, want_raws, ("P3", "P4", "P5")):
-        assert _rel_l2(got, want) <= 3e-2, (name, _rel_l2(got, want))
+        assert _rel_l2(got, want) <= 1e-2, (name, _rel_l2(got, want))
     pred = m._forward(imgs)[0].cpu().numpy()
     want = decode_ref.decode_anchor(want_raws, p.anchors, p.strides, 640, "v5")
     _check_pred(pred, want, 640)
@@ -138,7 +137,7 @@ def test_v5s_1280_vs_oracle_graph(gpu_device):
     with torch.no_grad():
         want_raws = [t.numpy() for t in v5_ref.body_forward(sd, torch.from_numpy(imgs_np))]
     for got, want, name in zip(raws, want_raws, ("P3", "P4", "P5")):
-        assert got.shape == want.shape and _rel_l2(got, want) <= 3e-2, (name, _rel_l2(got, want))
+        assert got.shape == want.shape and _rel_l2(got, want) <= 1e-2, (name, _rel_l2(got, want))
     pred_dev = m._forward(imgs)[0]
     pred = pred_dev.cpu().numpy()
     assert pred.shape == (1, 100800, 25)
