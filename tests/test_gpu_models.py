@@ -4,7 +4,8 @@ fp32 decode -> NMS, against the reference's golden outputs (small size) and the 
 bf16 tolerances (weights and activations rounded to bf16 through the whole conv chain, fp32 accumulate), as measured with
 scratch/tolerance_probe.py on all 23 models (profiles/r3_tolerance_probe.txt) plus a margin:
   raw head logits   relative L2 <= 1e-2 vs the fp32 reference (measured <= 4.3e-3); the RepVGG / v6 family <= 1.5e-2
-                    (measured <= 1.02e-2: forty re-parameterised blocks in a row, three summed branches each)
+                    (measured <= 1.02e-2: forty re-parameterised blocks in a row, three summed branches each); the v5
+                    face / pose graphs <= 2e-2 (measured 1.6e-2 on the finest head at 640 x 640)
   decoded boxes     |d| <= 0.5 px + 1 % for all but 0.2 % of the values, keypoints / landmarks the same, for EVERY family,
                     v3 / v4 widths and heights (exp(logit) x anchor) and the face / pose heads included; the anchor-free
                     v6 heads get + 3 % of the row's stride (their random-init boxes have sizes near zero, so a relative
@@ -39,7 +40,9 @@ def _row_stride(name, p, size):
 
 
 def _raw_tol(name):
-    return 1.5e-2 if name in V6_FAMILY else 1e-2
+    # v5 face / pose at 640 x 640: 1.6e-2 measured on the finest head (their random-init features reach the heads with a
+    # standard deviation near 10, which the damped head convs scale down together with the error)
+    return 1.5e-2 if name in V6_FAMILY else (2e-2 if name in ("v5face", "v5pose", "v5facem", "v5posex") else 1e-2)
 
 
 def _score_tol(name):
