@@ -302,7 +302,7 @@ TILING_CASES += _second_set_cases()
 # walked by one workgroup (stages 2) and one cout tile per workgroup (stages 3), and the stages-3 form of other kernels
 TILING_CASES += [(3, 1, 48, 128, 37, 29, True, (4, 4, 16, 4, 2)), (3, 1, 64, 296, 40, 40, True, (4, 4, 16, 4, 3)),
                  (3, 1, 32, 256, 20, 20, False, (4, 4, 16, 4, 2)), (3, 2, 64, 512, 40, 40, False, (1, 4, 16, 8, 3)),
-                 (1, 1, 128, 300, 20, 20, True, (2, 4, 64, 4, 3)), (3, 1, 32, 256, 23, 17, True, (2, 4, 16, 8, 3))]
+                 (1, 1, 128, 296, 20, 20, True, (2, 4, 64, 4, 3)), (3, 1, 32, 256, 23, 17, True, (2, 4, 16, 8, 3))]
 
 
 @pytest.mark.parametrize("k,s,cin,cout,H,W,use_res,tiling", TILING_CASES)

@@ -535,7 +535,8 @@ class Program:
                 m[0].pack(best[key])
                 m[0].to(device)
             if log is not None:
-                log(f"{key:28s} x{len(members)} " + "  ".join(f"{c}={t:.4f}" for t, c in results[:5]))
+                log(f"{key:28s} x{len(members)} " + "  ".join(f"{c}={t:.4f}" for t, c in results[:5])
+                    + "".join(f"  [{c}={t:.4f}]" for t, c in results[5:] if c[0] == 4))
         return best
 
     # ---- accounting ------------------------------------------------------------------------------
