@@ -298,11 +298,9 @@ def _second_set_cases():
 
 
 TILING_CASES += _second_set_cases()
-# the one-wavefront-per-SIMD tiling (128 pixels x 128 couts per wave), with a residual, ragged edges, several cout tiles
-# walked by one workgroup (stages 2) and one cout tile per workgroup (stages 3), and the stages-3 form of other kernels
-TILING_CASES += [(3, 1, 48, 128, 37, 29, True, (4, 4, 16, 4, 2)), (3, 1, 64, 296, 40, 40, True, (4, 4, 16, 4, 3)),
-                 (3, 1, 32, 256, 20, 20, False, (4, 4, 16, 4, 2)), (3, 2, 64, 512, 40, 40, False, (1, 4, 16, 8, 3)),
-                 (1, 1, 128, 296, 20, 20, True, (2, 4, 64, 4, 3)), (3, 1, 32, 256, 23, 17, True, (2, 4, 16, 8, 3))]
+# one cout tile per workgroup (stages 3) for each kernel family, with a residual, ragged edges and a partial last tile
+TILING_CASES += [(3, 2, 64, 512, 40, 40, False, (1, 4, 16, 8, 3)), (1, 1, 128, 296, 20, 20, True, (2, 4, 64, 4, 3)),
+                 (3, 1, 32, 256, 23, 17, True, (2, 4, 16, 8, 3)), (3, 1, 64, 296, 40, 40, True, (2, 4, 16, 4, 3))]
 
 
 @pytest.mark.parametrize("k,s,cin,cout,H,W,use_res,tiling", TILING_CASES)

@@ -96,7 +96,7 @@ extern "C" int yamd_conv_desc_tune(yamd_conv_desc *d, int mrep, int nrep, int ck
     YAMD_REQUIRE(d != nullptr, "null descriptor");
     YAMD_REQUIRE(nwaves == 4 || nwaves == 8, "nwaves=%d must be 4 or 8", nwaves);
     YAMD_REQUIRE(stages >= 1 && stages <= 3, "stages=%d must be 1, 2 or 3", stages);
-    YAMD_REQUIRE((mrep == 1 || mrep == 2 || mrep == 4) && (nrep == 1 || nrep == 2 || nrep == 4) && (ck == 16 || ck == 32 || ck == 64),
+    YAMD_REQUIRE((mrep == 1 || mrep == 2) && (nrep == 1 || nrep == 2 || nrep == 4) && (ck == 16 || ck == 32 || ck == 64),
                  "bad tiling mrep=%d nrep=%d ck=%d", mrep, nrep, ck);
     YAMD_REQUIRE(d->cin % ck == 0, "cin=%d is not a multiple of ck=%d", d->cin, ck);
     YAMD_REQUIRE(!d->out_f32, "the float-output kernel has one tiling");

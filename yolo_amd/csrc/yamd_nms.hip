@@ -223,6 +223,19 @@ constexpr int SEG_WAVES = SEG_THREADS / 64;
 constexpr int CELLS = 8192;                 // cells of the grouping: 2 size classes x 64 x 64 places
 constexpr int CELL_BITS = 13;
 
+// Phase timing of nms_segment_kernel for the profiling build (-DYAMD_NMS_PHASES, scratch/nms_phases.py): thread 0 of
+// every workgroup adds the shader-clock ticks between the marks to nms_phase_ticks.  Compiled out of the library.
+#ifdef YAMD_NMS_PHASES
+__device__ unsigned long long nms_phase_ticks[16];
+#define PH_DECL unsigned long long ph_t = clock64()
+#define PH(k) do { if (tid == 0) { const unsigned long long ph_n = clock64(); atomicAdd(&nms_phase_ticks[k], ph_n - ph_t); ph_t = ph_n; } } while (0)
+#define PH_COUNT(k, v) do { if (tid == 0) atomicAdd(&nms_phase_ticks[k], (unsigned long long)(v)); } while (0)
+#else
+#define PH_DECL
+#define PH(k)
+#define PH_COUNT(k, v)
+#endif
+
 // In-place bitonic sort, descending, of n (any n) 64-bit keys by one SEG_THREADS workgroup.  `a` may
 // point to LDS or to global memory.  The network only uses comparators that move the larger key to the
 // lower index (each merge starts with a mirror step), so the virtual padding "smaller than everything"
@@ -382,6 +395,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float coff = (float)cls * 4096.0f;
+    PH_DECL;
 
     // ---- 1. sort by key: in LDS when the bucket fits, else in place in global memory (skey)
     u32 npad = 8;
@@ -397,6 +411,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
     __syncthreads();
     if (in_lds) bitonic_sort_desc_blocked(S, n, npad, tid);
     else bitonic_sort_desc(S, n, tid);
+    PH(0);
 
     // ---- 2. sorted keys + offset boxes out, then the same boxes grouped by place: a counting sort into the 4096
     // cells of a 64x64 grid, cells numbered along a Morton curve, so that 64 consecutive boxes (a GROUP) lie close
@@ -476,6 +491,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             }
         }
         __syncthreads();                                // the sorted keys in LDS are dead from here
+        PH(1);
         if (grouped) {
             for (u32 c = tid; c < (u32)CELLS; c += SEG_THREADS) hist[c] = 0u;
             __syncthreads();
@@ -525,6 +541,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
         }
     }
     __syncthreads();
+    PH(2);
 
     // ---- sweep state in LDS (aliases the sort array)
     const u32 ng = (n + 63) / 64;                       // groups == tiles == mask words
@@ -613,6 +630,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
     u32 sp_cur = lane < (int)min(64u, n) ? posr[lane] : 0u;   // Morton position of this lane's tile box
     u64 key_cur = lane < (int)min(64u, n) ? skey[lane] : 0ull;
     __syncthreads();
+    PH(3);
 
     u32 nkept = 0;
     for (u32 t = 0; t < ng; ++t) {
@@ -644,8 +662,10 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             // every box of this tile is decided now: flag it so that later phases skip it
             if (inr) atomicOr(&rem[sp_cur >> 6], 1ull << (sp_cur & 63));
         }
+        PH(4);
         __syncthreads();
         const u32 nk = *s_nk;
+        PH(5);
         nkept += nk;
         // ---- next tile's data first (latency hides under C), then C(t), then A(t+1)
         const bool have_next = t + 1 < ng;
@@ -724,9 +744,12 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             const bool gone = (t + 1) * 64 + lane < n && ((rem[nsp >> 6] >> (nsp & 63)) & 1ull);
             phase_a(t + 1, bx, ar, __ballot(gone));
         }
+        PH(6);
         __syncthreads();
+        PH(7);
     }
     if (tid == 0) p.kcnt[b * p.nc + cls] = nkept;
+    PH_COUNT(8, 1); PH_COUNT(9, n); PH_COUNT(10, nkept);
 }
 
 // kept rows of class `cls`: global rank = own position + number of larger keys in every other class.
@@ -1279,3 +1302,15 @@ extern "C" int yamd_compact_rows(const float *rows, const int *counts, int batch
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
 }
+
+#ifdef YAMD_NMS_PHASES
+extern "C" int yamd_debug_nms_phases(unsigned long long *out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(nms_phase_ticks), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(nms_phase_ticks), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif

@@ -50,12 +50,6 @@ def candidates(k: int, s: int, cin: int, cout: int) -> List[Tuple[int, ...]]:
                             if stages == 3 and groups <= nrep:       # one cout tile: the same launch as stages 2
                                 continue
                             out.append((mrep, nrep, ck, nwaves, stages))
-    if k == 3 and s == 1 and groups >= 4 and cin % 16 == 0:
-        # one wavefront per SIMD with a 128-pixel x 128-cout register tile each (8 LDS fragment reads per 16 MFMAs
-        # instead of 6 per 8): the deep 3x3 layers, whose two-wave form keeps the LDS read port as busy as the matrix pipe
-        out.append((4, 4, 16, 4, 2))
-        if groups > 4:
-            out.append((4, 4, 16, 4, 3))
     return out
 
 
