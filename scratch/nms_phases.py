@@ -20,12 +20,12 @@ NAMES = ["sort", "boxes+sorted write", "grouping", "sweep set-up + A(0)", "B: wa
          "C + A(next): wave 0", "C + A: wait for slowest wave"]
 
 
-def build():
+def build(level=1):
     from yolo_amd import build as B
     B.build_library(verbose=False)
     os.makedirs(PROF_DIR, exist_ok=True)
     o = os.path.join(PROF_DIR, "yamd_nms.o")
-    subprocess.check_call([B._hipcc()] + B.COMMON + ["-ffp-contract=off", "-DYAMD_NMS_PHASES", "-c",
+    subprocess.check_call([B._hipcc()] + B.COMMON + ["-ffp-contract=off", f"-DYAMD_NMS_PHASES={level}", "-c",
                                                      os.path.join(B.CSRC, "yamd_nms.hip"), "-o", o])
     objs = [os.path.join(B.OBJ, s.replace(".hip", ".o")) for s, _ in B.SOURCES if s != "yamd_nms.hip"] + [o]
     subprocess.check_call([B._hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", PROF_LIB] + objs)
@@ -35,11 +35,12 @@ def build():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
+    ap.add_argument("--counters", action="store_true", help="with --build: count the sweep's work per wave too (slow)")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--model", default="v5s")
     args = ap.parse_args()
     if args.build:
-        return build()
+        return build(2 if args.counters else 1)
     import torch
     import bench
     import yolo_amd.lib as lib
@@ -60,7 +61,7 @@ def main():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     lib.check(prof.yamd_init(), "init")
-    p, model, _ = bench.build_model(args.model, "default")
+    p, model, _ = bench.build_model(args.model, "torch_default")
     model = model.to(dev).eval()
     images = bench.device_images(args.batch, p.img_size if hasattr(p, "img_size") else 640, 0, dev)
     raws = model.raw_heads(images)
@@ -81,6 +82,8 @@ def main():
               f"{tot / nb:.0f} ticks per bucket")
         for i, nm in enumerate(NAMES):
             print(f"    {nm:32s} {out[i] / nb:10.0f} ticks  {100.0 * out[i] / max(tot, 1):5.1f} %")
+        print(f"    per bucket: {out[11] / nb:.0f} (tile, group) bounding-box tests, {out[12] / nb:.0f} with kept boxes to apply, "
+              f"{out[13] / nb:.0f} (kept box, group) steps, {out[14] / nb:.0f} of them reach the division")
 
 
 if __name__ == "__main__":

@@ -40,6 +40,7 @@ struct NmsParams {
     const float *pred;
     int B, A, C, in_cxcywh, n_extra, nc, W, max_out;
     float hi, conf_thr, iou_thr;
+    float iou_hi, iou_lo;        // iou_thr (1 +- 2^-20): see IouBand
     u64 *tmp_key, *tmp_meta, *bkey, *skey, *kseg;
     float4 *sbox, *mbox;
     u32 *mrank, *posr;
@@ -197,25 +198,46 @@ __global__ __launch_bounds__(256) void nms_bucket_kernel(NmsParams p)
     p.bkey[b * p.A + p.cls_off[b * (p.nc + 1) + cls] + ticket] = key;
 }
 
-// suppression test of the torchvision CPU kernel: i = kept (higher score) box, j = candidate
-__device__ __forceinline__ float iou_inter(float ix1, float iy1, float ix2, float iy2, float jx1, float jy1, float jx2, float jy2)
+// Suppression test of the torchvision CPU kernel (i = kept, higher score box, j = candidate):
+//   w = max(0, min(ix2, jx2) - max(ix1, jx1)), h likewise, inter = w * h, ovr = inter / (ia + ja - inter), ovr > thr.
+// The sweep's boxes are class-offset boxes: clamped to [0, hi], then + cls * 4096 (which also turns a -0 into +0).
+// For non-negative finite floats the float order is the order of the bit patterns, so max / min can be integer
+// instructions; they return the very floats fmaxf / fminf return (and need no NaN quieting of their operands).
+__device__ __forceinline__ float max_pos(float a, float b) { return __uint_as_float(max(__float_as_uint(a), __float_as_uint(b))); }
+__device__ __forceinline__ float min_pos(float a, float b) { return __uint_as_float(min(__float_as_uint(a), __float_as_uint(b))); }
+__device__ __forceinline__ float iou_inter_pos(float ix1, float iy1, float ix2, float iy2, float jx1, float jy1, float jx2, float jy2)
 {
-    const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1);
-    const float xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
+    const float xx1 = max_pos(ix1, jx1), yy1 = max_pos(iy1, jy1);
+    const float xx2 = min_pos(ix2, jx2), yy2 = min_pos(iy2, jy2);
     const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
     return w * h;
 }
-__device__ __forceinline__ bool iou_ratio_gt(float inter, float ia, float ja, float thr)
+
+// `RN(inter / uni) > thr` without the division in all but borderline cases.  With hi = thr (1 + 2^-20) and
+// lo = thr (1 - 2^-20):  inter > RN(uni * hi + 1e-30)  implies  inter / uni > thr (1 + 2^-21), which is beyond the float
+// above thr, so the rounded quotient exceeds thr;  inter < RN(uni * lo - 1e-30)  implies  inter / uni < thr (1 - 2^-21),
+// so the rounded quotient is at most thr.  (Each fma rounds once, 2^-24 relative; the +-1e-30 keeps both statements
+// true where uni * thr would be subnormal: there neither comparison can hold.)  Everything else - quotients within
+// 2^-20 of the threshold, NaN, thr = 0, vanishing areas - is `open` and takes the division itself (iou_exact_gt), so
+// the predicate is the reference's for every input.
+struct IouBand {
+    float thr, hi, lo;
+};
+__device__ __forceinline__ float iou_union(float inter, float ia, float ja)
 {
     float uni = ia + ja;
     uni = uni - inter;
+    return uni;
+}
+__device__ __forceinline__ void iou_band_test(float inter, float uni, const IouBand &band, bool &gt, bool &open)
+{
+    gt = inter > __fmaf_rn(uni, band.hi, 1e-30f);
+    open = !gt && !(inter < __fmaf_rn(uni, band.lo, -1e-30f));
+}
+__device__ __forceinline__ bool iou_exact_gt(float inter, float uni, float thr)
+{
     const float ovr = inter / uni;
     return ovr > thr;
-}
-__device__ __forceinline__ bool iou_gt(float ix1, float iy1, float ix2, float iy2, float ia, float jx1, float jy1,
-                                       float jx2, float jy2, float ja, float thr)
-{
-    return iou_ratio_gt(iou_inter(ix1, iy1, ix2, iy2, jx1, jy1, jx2, jy2), ia, ja, thr);
 }
 
 constexpr int SEG_THREADS = 1024;           // 16 waves per bucket
@@ -227,13 +249,23 @@ constexpr int CELL_BITS = 13;
 // every workgroup adds the shader-clock ticks between the marks to nms_phase_ticks.  Compiled out of the library.
 #ifdef YAMD_NMS_PHASES
 __device__ unsigned long long nms_phase_ticks[16];
-#define PH_DECL unsigned long long ph_t = clock64()
-#define PH(k) do { if (tid == 0) { const unsigned long long ph_n = clock64(); atomicAdd(&nms_phase_ticks[k], ph_n - ph_t); ph_t = ph_n; } } while (0)
+// (the ticks are summed in registers and reach the global counters once per workgroup: an atomic per mark would queue
+// behind those of every other workgroup and be waited for at the next barrier)
+#define PH_DECL unsigned int ph_acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}; unsigned long long ph_t = clock64()
+#define PH(k) do { if (tid == 0) { const unsigned long long ph_n = clock64(); ph_acc[k] += (unsigned int)(ph_n - ph_t); ph_t = ph_n; } } while (0)
+#define PH_FLUSH do { if (tid == 0) for (int ph_k = 0; ph_k < 8; ++ph_k) atomicAdd(&nms_phase_ticks[ph_k], (unsigned long long)ph_acc[ph_k]); } while (0)
 #define PH_COUNT(k, v) do { if (tid == 0) atomicAdd(&nms_phase_ticks[k], (unsigned long long)(v)); } while (0)
+#if YAMD_NMS_PHASES > 1   // work counters of every wave as well: they slow the kernel down, the ticks of such a run mean nothing
+#define PH_WAVE_COUNT(k, v) do { if (lane == 0) atomicAdd(&nms_phase_ticks[k], (unsigned long long)(v)); } while (0)
+#else
+#define PH_WAVE_COUNT(k, v)
+#endif
 #else
 #define PH_DECL
 #define PH(k)
+#define PH_FLUSH
 #define PH_COUNT(k, v)
+#define PH_WAVE_COUNT(k, v)
 #endif
 
 // In-place bitonic sort, descending, of n (any n) 64-bit keys by one SEG_THREADS workgroup.  `a` may
@@ -358,6 +390,12 @@ __device__ __forceinline__ u32 spread10(u32 v)   // 10 bits -> every second bit
 
 __device__ __forceinline__ float rl(float v, int lane) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane)); }
 
+// Element `i` of a wave-uniform array through a 32-bit byte offset (i * sizeof(T) < 2^32 is the caller's promise): the
+// access then takes the base from scalar registers and one vector register for the offset, instead of a 64-bit
+// address in two vector registers per access that is in flight.
+template <typename T>
+__device__ __forceinline__ T &at32(T *base, u32 i) { return *(T *)((char *)base + i * (u32)sizeof(T)); }
+
 // One 16-wave workgroup per (class, image) bucket.
 //  1. sort the bucket's keys (descending = the stable descending score order),
 //  2. write keys / class-offset boxes in that order, then group the same boxes by place (counting sort into
@@ -381,9 +419,11 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
     // heavy buckets are those of a few classes, so consecutive blocks must be different images of one class
     const int cls = blockIdx.y;
     const long long b = blockIdx.x;
-    const u32 n = p.cls_count[b * p.nc + cls];
+    // (loaded by vector instructions, but the same for every lane: in scalar registers, and the bucket's array bases
+    // below with them, they cost no vector registers)
+    const u32 n = (u32)__builtin_amdgcn_readfirstlane((int)p.cls_count[b * p.nc + cls]);
     if (n == 0) return;
-    const u32 off = p.cls_off[b * (p.nc + 1) + cls];
+    const u32 off = (u32)__builtin_amdgcn_readfirstlane((int)p.cls_off[b * (p.nc + 1) + cls]);
     const long long base = b * p.A + off;
     const u64 *keys = p.bkey + base;
     u64 *skey = p.skey + base;
@@ -453,9 +493,10 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
         }
     };
     if (in_lds) {
-        // at most RPT ranks per thread (r = tid + 1024 q): cells and tickets stay in registers
+        // at most RPT ranks per thread (r = tid + 1024 q): cells and tickets stay in registers, one word for both
+        // (cell < 2^13, ticket < n <= 2^13)
         constexpr int RPT = 8192 / SEG_THREADS, RH = 1;
-        u32 cq[RPT], tq[RPT];
+        u32 cq[RPT];
         // one rank at a time: the registers of more rows in flight would cost the second workgroup per compute unit
 #pragma unroll
         for (int h = 0; h < RPT / RH; ++h) {
@@ -483,12 +524,13 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
                 row_box(raw[q], p.in_cxcywh, p.hi, x1, y1, x2, y2);
                 const float4 ob = make_float4(x1 + coff, y1 + coff, x2 + coff, y2 + coff);
                 cq[h * RH + q] = cell_of(x1, y1, x2, y2);
-                if (r < n) {
-                    skey[r] = kq[q];
-                    sbox[r] = ob;
-                    if (!grouped) { mrank[r] = r; posr[r] = r; mbox[r] = ob; }
+                if (r < n) {                            // r < 8192
+                    at32(skey, r) = kq[q];
+                    at32(sbox, r) = ob;
+                    if (!grouped) { at32(mrank, r) = r; at32(posr, r) = r; at32(mbox, r) = ob; }
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);          // (rounds interleaved by the scheduler need more than 64 registers)
         }
         __syncthreads();                                // the sorted keys in LDS are dead from here
         PH(1);
@@ -497,7 +539,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < RPT; ++q)
-                if (tid + SEG_THREADS * q < n) tq[q] = atomicAdd(&hist[cq[q]], 1u);
+                if (tid + SEG_THREADS * q < n) cq[q] |= atomicAdd(&hist[cq[q]], 1u) << CELL_BITS;
             __syncthreads();
             scan_cells();
             __syncthreads();
@@ -505,10 +547,10 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             for (int q = 0; q < RPT; ++q) {
                 const u32 r = tid + SEG_THREADS * q;
                 if (r < n) {
-                    const u32 sp = hist[cq[q]] + tq[q];
-                    mrank[sp] = r;
-                    posr[r] = sp;
-                    mbox[sp] = sbox[r];                 // this thread's own store above
+                    const u32 sp = hist[cq[q] & (u32)(CELLS - 1)] + (cq[q] >> CELL_BITS);
+                    at32(mrank, sp) = r;
+                    at32(posr, r) = sp;
+                    at32(mbox, sp) = at32(sbox, r);     // this thread's own store above
                 }
             }
         }
@@ -544,12 +586,14 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
     PH(2);
 
     // ---- sweep state in LDS (aliases the sort array)
+    IouBand band;
+    band.thr = p.iou_thr; band.hi = p.iou_hi; band.lo = p.iou_lo;
     const u32 ng = (n + 63) / 64;                       // groups == tiles == mask words
     float4 *gbb = (float4 *)smem_seg;                   // ng group bounding boxes
     float4 *kb = gbb + ng;                              // 64 kept boxes of the current tile
-    u64 *rem = (u64 *)(kb + 64);                        // ng removed/decided-bit words (by Morton position)
-    u64 *colmask = rem + ng;                            // 64
-    u32 *gmax = (u32 *)(colmask + 64);                  // ng: largest score rank inside the group
+    unsigned char *rowb = (unsigned char *)(kb + 64);   // 64 x 16: the tile's suppression matrix, row j = 16 nibbles
+    u64 *rem = (u64 *)(rowb + 64 * SEG_WAVES);          // ng removed/decided-bit words (by Morton position)
+    u32 *gmax = (u32 *)(rem + ng);                      // ng: largest score rank inside the group
     float *ka = (float *)(gmax + ng);                   // 64 areas
     u32 *s_nk = (u32 *)(ka + 64);
     for (u32 g = wave; g < ng; g += SEG_WAVES) {
@@ -601,22 +645,35 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
         lbox[(g - cbase) * 64 + lane] = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    // columns [4*wave, 4*wave+4) of tile `t`'s suppression matrix: bit j of column i = box i removes box j > i
+    // columns [4*wave, 4*wave+4) of tile `t`'s suppression matrix (box i removes box j > i), stored by ROW: lane j
+    // writes the four bits "i removes me" of this wave's columns as byte `wave` of its 16-byte row, so that bit i of
+    // the 64-bit row j is nibble i / 4, bit i % 4.
     constexpr int CPW = 64 / SEG_WAVES;
-    // `dead`: boxes of the tile that are already removed; a removed box suppresses nothing, its column is never read
+    static_assert(CPW == 4, "a row is 16 nibbles");
+    // `dead`: boxes of the tile that are already removed; a removed box suppresses nothing, its column stays zero
     auto phase_a = [&](u32 t, const float4 bx, const float ar, const u64 dead) __attribute__((always_inline)) {
         const u32 tn = min(64u, n - t * 64);
         const bool inr = (u32)lane < tn;
+        u32 nib = 0u;
 #pragma unroll
         for (int ii = 0; ii < CPW; ++ii) {
             const int i = wave * CPW + ii;
             if ((u32)i < tn && !((dead >> i) & 1ull)) {
-                const float ix1 = rl(bx.x, i), iy1 = rl(bx.y, i), ix2 = rl(bx.z, i), iy2 = rl(bx.w, i), ia = rl(ar, i);
-                const bool sup = inr && lane > i && iou_gt(ix1, iy1, ix2, iy2, ia, bx.x, bx.y, bx.z, bx.w, ar, p.iou_thr);
-                const u64 cm = __ballot(sup);
-                if (lane == 0) colmask[i] = cm;
+                const float inter = iou_inter_pos(rl(bx.x, i), rl(bx.y, i), rl(bx.z, i), rl(bx.w, i), bx.x, bx.y, bx.z, bx.w);
+                const float uni = iou_union(inter, rl(ar, i), ar);
+                const bool later = inr && lane > i;
+                bool sup, open;
+                iou_band_test(inter, uni, band, sup, open);
+                if (__ballot(open && later) != 0ull) sup = iou_exact_gt(inter, uni, band.thr);
+                nib |= (sup && later) ? (1u << ii) : 0u;
             }
         }
+        rowb[lane * SEG_WAVES + wave] = (unsigned char)nib;
+    };
+    // 16 bytes with one nibble each -> 64 bits: four bytes of a word fold to 16 bits in two steps
+    auto fold4 = [](u32 x) __attribute__((always_inline)) {
+        x = (x | (x >> 4)) & 0x00ff00ffu;
+        return (x | (x >> 8)) & 0x0000ffffu;
     };
     auto tile_box = [&](u32 t) __attribute__((always_inline)) {
         const u32 j = t * 64 + lane;
@@ -639,19 +696,16 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
         if (wave == 0) {
             const bool inr = (u32)lane < tn;
             const bool alive = inr && !((rem[sp_cur >> 6] >> (sp_cur & 63)) & 1ull);
-            const u64 mycol = inr ? colmask[lane] : 0ull;
-            const u32 clo = (u32)mycol, chi = (u32)(mycol >> 32);
-            u64 m = __ballot(alive);
-            u64 cand = m & __ballot(mycol != 0ull);     // only boxes that remove something need a serial step
-            while (cand) {
-                const int i = __ffsll((long long)cand) - 1;
-                cand &= cand - 1ull;
-                if ((m >> i) & 1ull) {
-                    const u64 c = ((u64)(u32)__builtin_amdgcn_readlane(chi, i) << 32) | (u64)(u32)__builtin_amdgcn_readlane(clo, i);
-                    m &= ~c;
-                }
-            }
-            const u64 kept = m;
+            const uint4 rw = *(const uint4 *)(rowb + lane * SEG_WAVES);
+            const u32 rlo = fold4(rw.x) | (fold4(rw.y) << 16), rhi = fold4(rw.z) | (fold4(rw.w) << 16);
+            // greedy pass as a fixed point: box j is kept iff it is alive and no KEPT box i < j removes it.  A row only
+            // holds bits i < j, so position j is final once positions < j are: every round settles at least one more
+            // position, the fixed point is unique, and it is what the serial loop over i produces.
+            u64 kept = __ballot(alive), prev;
+            do {
+                prev = kept;
+                kept = __ballot(alive && ((rlo & (u32)prev) | (rhi & (u32)(prev >> 32))) == 0u);
+            } while (kept != prev);
             if ((kept >> lane) & 1ull) {
                 const u32 pos = (u32)__popcll(kept & ((1ull << lane) - 1ull));
                 kb[pos] = bx;
@@ -683,7 +737,11 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
         if (nk > 0 && have_next) {
             const u32 first_later = (t + 1) * 64;
             float4 kx = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((u32)lane < nk) kx = kb[lane];
+            float kar = 0.f;
+            if ((u32)lane < nk) {
+                kx = kb[lane];
+                kar = ka[lane];
+            }
             // kept boxes of this tile against one group's boxes (fetched by `boxes` once the group is known to need them)
             auto apply = [&](const u32 g, const u32 part, const u32 parts, auto boxes) __attribute__((always_inline)) {
                 const float4 bb = gbb[g];
@@ -701,23 +759,34 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
                     }
                     rel = m;
                 }
+                PH_WAVE_COUNT(11, 1);
                 if (rel == 0ull) return;
                 const bool todo = g * 64 + lane < n && !((rem[g] >> lane) & 1ull);
                 if (__ballot(todo) == 0ull) return;
                 const float4 jx = boxes();
                 const float ja = (jx.z - jx.x) * (jx.w - jx.y);
-                bool sup = false;
+                PH_WAVE_COUNT(12, 1);
+                PH_WAVE_COUNT(13, __popcll(rel));
+                // the kept boxes come out of the lanes' registers (lane k holds kept box k); pairs the band test leaves
+                // open are rare and wait in `redo` for the division, so that the loop has no branch but its own
+                u64 supm = 0ull, redo = 0ull;
                 while (rel) {
                     const int k = __ffsll((long long)rel) - 1;
                     rel &= rel - 1ull;
-                    const float4 qb = kb[k];
-                    // a kept box that touches the group's bounding box but none of its boxes: no lane has an
-                    // intersection, and a zero intersection never suppresses (the threshold is >= 0): skip the division
-                    const float inter = iou_inter(qb.x, qb.y, qb.z, qb.w, jx.x, jx.y, jx.z, jx.w);
-                    if (__ballot(inter > 0.0f) == 0ull) continue;
-                    sup = sup || iou_ratio_gt(inter, ka[k], ja, p.iou_thr);
+                    const float inter = iou_inter_pos(rl(kx.x, k), rl(kx.y, k), rl(kx.z, k), rl(kx.w, k), jx.x, jx.y, jx.z, jx.w);
+                    const float uni = iou_union(inter, rl(kar, k), ja);
+                    bool gt, open;
+                    iou_band_test(inter, uni, band, gt, open);
+                    supm |= __ballot(gt);
+                    redo |= __ballot(open && todo) != 0ull ? 1ull << k : 0ull;
                 }
-                const u64 sm = __ballot(sup && todo);
+                while (redo) {
+                    const int k = __ffsll((long long)redo) - 1;
+                    redo &= redo - 1ull;
+                    const float inter = iou_inter_pos(rl(kx.x, k), rl(kx.y, k), rl(kx.z, k), rl(kx.w, k), jx.x, jx.y, jx.z, jx.w);
+                    supm |= __ballot(iou_exact_gt(inter, iou_union(inter, rl(kar, k), ja), band.thr));
+                }
+                const u64 sm = supm & __ballot(todo);
                 if (lane == 0 && sm) atomicOr(&rem[g], sm);
             };
             auto cached = [&](const u32 g) __attribute__((always_inline)) {
@@ -749,7 +818,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
         PH(7);
     }
     if (tid == 0) p.kcnt[b * p.nc + cls] = nkept;
-    PH_COUNT(8, 1); PH_COUNT(9, n); PH_COUNT(10, nkept);
+    PH_FLUSH; PH_COUNT(8, 1); PH_COUNT(9, n); PH_COUNT(10, nkept);
 }
 
 // kept rows of class `cls`: global rank = own position + number of larger keys in every other class.
@@ -1186,7 +1255,7 @@ int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, 
     int sort_cap = 8;
     while (sort_cap < a && sort_cap < 8192) sort_cap <<= 1;
     const size_t ngmax = (size_t)(a + 63) / 64;
-    const size_t sweep_lds = ngmax * (16 + 8 + 4) + 64 * (16 + 8 + 4) + 16;
+    const size_t sweep_lds = ngmax * (16 + 8 + 4) + 64 * (16 + SEG_WAVES + 4) + 16;
     const size_t sort_lds = (size_t)sort_cap * 9;          // 8 bytes per key + one spare slot per 8 keys
     size_t slds = sort_lds > sweep_lds ? sort_lds : sweep_lds;
     const size_t group_lds = (size_t)(CELLS + SEG_WAVES) * 4;
@@ -1228,6 +1297,8 @@ int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, 
     float tf = (float)iou_thr;
     if ((double)tf > iou_thr) tf = nextafterf(tf, -INFINITY);
     p.iou_thr = tf;
+    p.iou_hi = tf * (1.0f + 0x1p-20f);
+    p.iou_lo = tf * (1.0f - 0x1p-20f);
     p.tmp_key = (u64 *)(ws + L.tmp_key);
     p.tmp_meta = (u64 *)(ws + L.tmp_meta);
     p.bkey = (u64 *)(ws + L.bkey);
