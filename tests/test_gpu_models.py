@@ -6,8 +6,9 @@ scratch/tolerance_probe.py on all 23 models (profiles/r3_tolerance_probe.txt) pl
   raw head logits   relative L2 <= 1e-2 vs the fp32 reference (measured <= 4.3e-3); the RepVGG / v6 family <= 1.5e-2
                     (measured <= 1.02e-2: forty re-parameterised blocks in a row, three summed branches each); the v5
                     face / pose graphs <= 2e-2 (measured 1.6e-2 on the finest head at 640 x 640)
-  decoded boxes     |d| <= 0.5 px + 1 % for all but 0.2 % of the values, keypoints / landmarks the same, for EVERY family,
-                    v3 / v4 widths and heights (exp(logit) x anchor) and the face / pose heads included; the anchor-free
+  decoded boxes     |d| <= 0.5 px + 1 % for all but 0.2 % of the values, keypoints / landmarks the same, for every family,
+                    v3 / v4 widths and heights (exp(logit) x anchor) and the face / pose heads included, except v5face /
+                    v5pose (+ 4 % of the row's anchor, see _row_anchor); the anchor-free
                     v6 heads get + 3 % of the row's stride (their random-init boxes have sizes near zero, so a relative
                     allowance means nothing; measured need <= 2.7 % of a cell)
   scores            |d| <= 1e-2 likewise (measured <= 7.7e-3); v6 family 2e-2 (measured <= 1.6e-2)
@@ -37,6 +38,20 @@ def _row_stride(name, p, size):
     if name in V6_FAMILY:
         return np.concatenate([np.full((size // s) ** 2, s, np.float32) for s in p.strides])
     return None
+
+
+def _row_anchor(name, p, size):
+    """per-row larger anchor side (pixels) for v5face / v5pose, None elsewhere: with the full-size goldens' seed their
+    random-init graphs reach the heads with features of mean >> spread, which the head convs cancel: the logits carry
+    the bf16 rounding of the large values (relative L2 1.5e-2 - 1.7e-2 with every fused form and the tuning table
+    switched off as well, scratch/diag_fuse.py; 1e-3 for the same graphs with other seeds and for the m / x widths)"""
+    if name not in ("v5face", "v5pose"):
+        return None
+    out = []
+    for lvl, s in enumerate(p.strides):
+        for aw, ah in p.anchors[3 * lvl:3 * lvl + 3]:
+            out.append(np.full((size // s) ** 2, max(aw, ah), np.float32))
+    return np.concatenate(out)
 
 
 def _raw_tol(name):
@@ -82,7 +97,7 @@ def test_small_vs_reference_golden(name, gpu_device):
         assert _rel_l2(got, g[f"raw{i}"]) <= _raw_tol(name), (i, _rel_l2(got, g[f"raw{i}"]))
     pred = m._forward(imgs)[0].cpu().numpy()
     assert pred.shape == g["pred"].shape
-    _check_pred(pred, g["pred"], size, POINTS.get(name, 0), _row_stride(name, p, size), _score_tol(name))
+    _check_pred(pred, g["pred"], size, POINTS.get(name, 0), _row_stride(name, p, size), _score_tol(name), _row_anchor(name, p, size))
     out = m.predict({"batch_images": imgs})["predicts"]
     want = split_rows(g["counts"], g["rows"])
     for a, b in zip(out, want):
@@ -118,10 +133,10 @@ def test_full_size_vs_oracle_graph(name, gpu_device):
     for i, (got, want) in enumerate(zip(raws, want_raws)):
         assert _rel_l2(got, want) <= _raw_tol(name), (i, _rel_l2(got, want))
     pred = m._forward(imgs)[0].cpu().numpy()
-    _check_pred(pred, ref["decode"](want_raws, p, False), size, POINTS.get(name, 0), _row_stride(name, p, size), _score_tol(name))
-    rs = _row_stride(name, p, size)
+    rs, ra = _row_stride(name, p, size), _row_anchor(name, p, size)
+    _check_pred(pred, ref["decode"](want_raws, p, False), size, POINTS.get(name, 0), rs, _score_tol(name), ra)
     _check_pred(pred[:1, g["pred_rows"]], g["pred"], size, POINTS.get(name, 0),
-                None if rs is None else rs[g["pred_rows"]], _score_tol(name))
+                None if rs is None else rs[g["pred_rows"]], _score_tol(name), None if ra is None else ra[g["pred_rows"]])
 
 
 def test_v8_feed_forward_keys(gpu_device):

@@ -158,6 +158,30 @@ def test_nms_random_vs_c_oracle(gpu_device, B, A, nc, clusters, conf):
     _check_rows(rows, counts, want, index, want_idx)
 
 
+@pytest.mark.parametrize("nc,thr", [(1, 0.3), (3, 0.45), (2, 0.0)])
+def test_nms_xyxy_with_inverted_and_empty_boxes(gpu_device, nc, thr):
+    """xyxy rows as an anchor-free head with untrained weights emits them: a third of the boxes have x2 < x1 or
+    y2 < y1 (negative "areas", unions <= 0), some are empty, some lie outside the image and clamp to its border; the
+    overlap test must still be the reference's division for them.  Several tiles per bucket."""
+    from oracle import postprocess as pp
+    from yolo_amd import torch_utils as tu
+    rng = np.random.RandomState(11 + nc)
+    A = 1500
+    c = rng.uniform(-20, 340, (2, A, 2))
+    half = rng.uniform(4, 60, (2, A, 2))
+    x1y1, x2y2 = c - half, c + half
+    flip = rng.uniform(size=(2, A)) < 0.33
+    x1y1[flip], x2y2[flip] = x2y2[flip], x1y1[flip].copy()
+    empty = rng.uniform(size=(2, A)) < 0.05
+    x2y2[empty] = x1y1[empty]
+    obj = rng.uniform(0.2, 1.0, (2, A, 1))
+    cls = rng.uniform(0.3, 1.0, (2, A, nc))
+    pred = np.concatenate((x1y1, x2y2, obj, cls), -1).astype(np.float32)
+    want, want_idx = pp.non_max_suppression(pred, 320.0, "xyxy", 0.1, thr, return_index=True)
+    rows, counts, index = tu.nms_batched(torch.from_numpy(pred).to(gpu_device), 320.0, "xyxy", 0.1, thr, 0, want_index=True)
+    _check_rows(rows, counts, want, index, want_idx)
+
+
 def test_nms_allpass_single_class_big_segment(gpu_device):
     """every anchor passes and falls into ONE class: the longest sequential sweep (segment = A boxes)"""
     from oracle import postprocess as pp

@@ -30,18 +30,22 @@ def _rel_l2(a, b):
     return float(np.linalg.norm((a - b).astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
 
 
-def _check_pred(got, want, img, point_num=0, row_stride=None, score_tol=1e-2):
+def _check_pred(got, want, img, point_num=0, row_stride=None, score_tol=1e-2, row_anchor=None):
     """Decoded tensor against the fp32 reference: boxes (and keypoints) within 0.5 px + 1 %, scores within ``score_tol``,
     for all but 0.2 % of the values.  row_stride: per-row stride of the anchor-free v6 heads, whose box columns are (raw
     logit) x stride with box sizes near zero at random init (a relative allowance means nothing there): 3 % of a grid cell
-    is added (measured need: at most 2.7 %, scratch/tolerance_probe.py)."""
+    is added (measured need: at most 2.7 %, scratch/tolerance_probe.py).  row_anchor: per-row larger anchor side for the
+    two graphs whose logits carry a bf16 error of 1.5e-2 (see test_gpu_models._raw_tol): sizes are (2 sigmoid)^2 x anchor
+    and landmarks logit x anchor, so 4 % of the anchor is added to both (measured need: 3.5 % of the size itself)."""
     extra = 0.0 if row_stride is None else 0.03 * np.asarray(row_stride, np.float32)[None, :, None]
+    if row_anchor is not None:
+        extra = 0.04 * np.asarray(row_anchor, np.float32)[None, :, None]
     box_tol = 0.5 + 0.01 * np.abs(want[..., :4]) + extra
     bad = np.abs(got[..., :4] - want[..., :4]) > box_tol
     assert bad.mean() < 2e-3, f"box mismatch fraction {bad.mean()}"
     if point_num:   # keypoint / landmark coordinates (pixels) sit between obj and the confidences: box tolerance
         k0, k1 = 5, 5 + 2 * point_num
-        badp = np.abs(got[..., k0:k1] - want[..., k0:k1]) > 0.5 + 0.01 * np.abs(want[..., k0:k1])
+        badp = np.abs(got[..., k0:k1] - want[..., k0:k1]) > 0.5 + 0.01 * np.abs(want[..., k0:k1]) + (0.0 if row_anchor is None else extra)
         assert badp.mean() < 2e-3, f"keypoint mismatch fraction {badp.mean()}"
         got = np.concatenate((got[..., :k0], got[..., k1:]), -1)
         want = np.concatenate((want[..., :k0], want[..., k1:]), -1)

@@ -86,7 +86,6 @@ __device__ __forceinline__ void row_best(const float *cls, int nc, float &best, 
 }
 
 constexpr int FROWS = 256;
-constexpr int REGQ = 2;   // groups per wave whose boxes are kept in registers during the NMS sweep
 
 __global__ __launch_bounds__(256) void nms_filter_kernel(NmsParams p)
 {
@@ -218,8 +217,8 @@ __device__ __forceinline__ float iou_inter_pos(float ix1, float iy1, float ix2, 
 // above thr, so the rounded quotient exceeds thr;  inter < RN(uni * lo - 1e-30)  implies  inter / uni < thr (1 - 2^-21),
 // so the rounded quotient is at most thr.  (Each fma rounds once, 2^-24 relative; the +-1e-30 keeps both statements
 // true where uni * thr would be subnormal: there neither comparison can hold.)  Everything else - quotients within
-// 2^-20 of the threshold, NaN, thr = 0, vanishing areas - is `open` and takes the division itself (iou_exact_gt), so
-// the predicate is the reference's for every input.
+// 2^-20 of the threshold, NaN, thr = 0, vanishing or negative areas - is `open` and takes the division itself
+// (iou_exact_gt), so the predicate is the reference's for every input.
 struct IouBand {
     float thr, hi, lo;
 };
@@ -231,8 +230,11 @@ __device__ __forceinline__ float iou_union(float inter, float ia, float ja)
 }
 __device__ __forceinline__ void iou_band_test(float inter, float uni, const IouBand &band, bool &gt, bool &open)
 {
-    gt = inter > __fmaf_rn(uni, band.hi, 1e-30f);
-    open = !gt && !(inter < __fmaf_rn(uni, band.lo, -1e-30f));
+    // both implications divide by uni: they need uni > 0.  Boxes with x2 < x1 or y2 < y1 (an xyxy input may hold them)
+    // have negative "areas" and can make uni <= 0 or NaN: such pairs are open as well
+    const bool pos = uni > 0.0f;
+    gt = pos && inter > __fmaf_rn(uni, band.hi, 1e-30f);
+    open = !gt && !(pos && inter < __fmaf_rn(uni, band.lo, -1e-30f));
 }
 __device__ __forceinline__ bool iou_exact_gt(float inter, float uni, float thr)
 {
@@ -497,6 +499,10 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
         // (cell < 2^13, ticket < n <= 2^13)
         constexpr int RPT = 8192 / SEG_THREADS, RH = 1;
         u32 cq[RPT];
+        // (a copy of the thread index the compiler cannot see through: addresses formed from it here are not shared with
+        // the later phases and do not stay in registers, or spill, across the loops in between)
+        u32 tl = (u32)tid;
+        asm volatile("" : "+v"(tl));
         // one rank at a time: the registers of more rows in flight would cost the second workgroup per compute unit
 #pragma unroll
         for (int h = 0; h < RPT / RH; ++h) {
@@ -504,12 +510,12 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             float raw[RH][4];
 #pragma unroll
             for (int q = 0; q < RH; ++q) {
-                const u32 r = tid + SEG_THREADS * (h * RH + q);
+                const u32 r = tl + SEG_THREADS * (h * RH + q);
                 kq[q] = r < n ? S[lds_slot(r)] : 0ull;
             }
 #pragma unroll
             for (int q = 0; q < RH; ++q) {
-                const u32 r = tid + SEG_THREADS * (h * RH + q);
+                const u32 r = tl + SEG_THREADS * (h * RH + q);
                 if (r < n) {
                     const float *row = p.pred + (b * p.A + (0xFFFFFFFFu - (u32)kq[q])) * (long long)p.C;
                     raw[q][0] = row[0]; raw[q][1] = row[1]; raw[q][2] = row[2]; raw[q][3] = row[3];
@@ -519,7 +525,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             }
 #pragma unroll
             for (int q = 0; q < RH; ++q) {
-                const u32 r = tid + SEG_THREADS * (h * RH + q);
+                const u32 r = tl + SEG_THREADS * (h * RH + q);
                 float x1, y1, x2, y2;
                 row_box(raw[q], p.in_cxcywh, p.hi, x1, y1, x2, y2);
                 const float4 ob = make_float4(x1 + coff, y1 + coff, x2 + coff, y2 + coff);
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
                 if (r < n) {                            // r < 8192
                     at32(skey, r) = kq[q];
                     at32(sbox, r) = ob;
-                    if (!grouped) { at32(mrank, r) = r; at32(posr, r) = r; at32(mbox, r) = ob; }
+                    if (!grouped && h == 0) { at32(mrank, r) = r; at32(posr, r) = r; at32(mbox, r) = ob; }      // n <= 64
                 }
             }
             __builtin_amdgcn_sched_barrier(0);          // (rounds interleaved by the scheduler need more than 64 registers)
@@ -539,13 +545,17 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             __syncthreads();
 #pragma unroll
             for (int q = 0; q < RPT; ++q)
-                if (tid + SEG_THREADS * q < n) cq[q] |= atomicAdd(&hist[cq[q]], 1u) << CELL_BITS;
+                if (tl + SEG_THREADS * q < n) cq[q] |= atomicAdd(&hist[cq[q]], 1u) << CELL_BITS;
             __syncthreads();
             scan_cells();
             __syncthreads();
+            // (a second copy: with the index of the stores above the compiler would keep all eight boxes in registers
+            // for the load below instead of reading them back)
+            u32 tr = (u32)tid;
+            asm volatile("" : "+v"(tr));
 #pragma unroll
             for (int q = 0; q < RPT; ++q) {
-                const u32 r = tid + SEG_THREADS * q;
+                const u32 r = tr + SEG_THREADS * q;
                 if (r < n) {
                     const u32 sp = hist[cq[q] & (u32)(CELLS - 1)] + (cq[q] >> CELL_BITS);
                     at32(mrank, sp) = r;
@@ -617,33 +627,22 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
         }
     }
 
-    // Boxes of this wave's first REGQ groups (g = wave + 16q) stay in registers for the whole sweep, the next
-    // p.cache_groups groups of the bucket in LDS: phase C touches global memory only for what lies beyond both.
-    float4 rb[REGQ];
-#pragma unroll
-    for (int q = 0; q < REGQ; ++q) {
-        const u32 s = (wave + SEG_WAVES * q) * 64 + lane;
-        rb[q] = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // the next groups wait in LDS behind the sweep state (the sort array is dead): a lane reads back only what it
-    // wrote itself, so no barrier orders these stores
-    // The last `ng % 16` groups of a bucket do not fill a round of one group per wave: each of them is shared by
-    // 16 / (ng % 16) waves that split the kept boxes between them (a bucket of 20 groups otherwise costs two rounds
-    // of which the second keeps 4 of the 16 waves busy).  Those waves are not the groups' owners, so the boxes come
-    // from the LDS cache, which therefore starts at group `cbase` = 16 (0 for buckets of fewer than 16 groups); the
-    // barrier before the first tile orders its stores.
-    constexpr u32 G0 = SEG_WAVES * REGQ;
-    const u32 full = ng & ~(u32)(SEG_WAVES - 1);
-    const u32 tail = ng - full;
-    const u32 tparts = tail ? (u32)SEG_WAVES / tail : 1u;
-    const u32 tgroup = full + (u32)wave / tparts, tpart = (u32)wave % tparts;
-    const u32 cbase = min(full, (u32)SEG_WAVES);
+    // The first p.cache_groups groups' boxes wait in LDS behind the sweep state (the sort array is dead), so that phase C
+    // touches global memory only for what lies beyond; the barrier before the first tile orders these stores.
     float4 *lbox = (float4 *)(smem_seg + p.cache_off);
-    const u32 ncache = min((u32)p.cache_groups, ng - cbase);
-    for (u32 g = cbase + wave; g < cbase + ncache; g += SEG_WAVES) {
+    const u32 ncache = min((u32)p.cache_groups, ng);
+    for (u32 g = wave; g < ncache; g += SEG_WAVES) {
         const u32 s = g * 64 + lane;
-        lbox[(g - cbase) * 64 + lane] = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        lbox[g * 64 + lane] = s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // Phase C hands groups to waves by ticket (an LDS counter that wave 0 resets in phase B): the groups' costs differ
+    // by what the kept boxes of a tile touch, and a fixed assignment left the average wave waiting at the tile's second
+    // barrier for as long as it had worked.  Ticket k is group ng - 1 - (k >> tshift) - the groups of large boxes, which
+    // most kept boxes touch, lie last in the Morton order and go first - and share k & (2^tshift - 1) of its kept boxes:
+    // a bucket of fewer than 16 groups splits every group between 2^tshift waves.
+    u32 *s_tk = s_nk + 1;
+    const u32 tshift = ng >= (u32)SEG_WAVES ? 0u : (u32)(31 - __clz((int)((u32)SEG_WAVES / ng)));
+    const u32 ntk = ng << tshift;
 
     // columns [4*wave, 4*wave+4) of tile `t`'s suppression matrix (box i removes box j > i), stored by ROW: lane j
     // writes the four bits "i removes me" of this wave's columns as byte `wave` of its 16-byte row, so that bit i of
@@ -712,7 +711,10 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
                 ka[pos] = ar;
                 kseg[nkept + pos] = key_cur;
             }
-            if (lane == 0) *s_nk = (u32)__popcll(kept);
+            if (lane == 0) {
+                *s_nk = (u32)__popcll(kept);
+                *s_tk = 0u;
+            }
             // every box of this tile is decided now: flag it so that later phases skip it
             if (inr) atomicOr(&rem[sp_cur >> 6], 1ull << (sp_cur & 63));
         }
@@ -789,20 +791,24 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
                 const u64 sm = supm & __ballot(todo);
                 if (lane == 0 && sm) atomicOr(&rem[g], sm);
             };
-            auto cached = [&](const u32 g) __attribute__((always_inline)) {
-                const u32 s = g * 64 + lane;
-                if (g - cbase < ncache) return lbox[(g - cbase) * 64 + lane];
-                return s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+            auto ticket = [&]() __attribute__((always_inline)) {
+                u32 v = 0u;
+                if (lane == 0) v = atomicAdd(s_tk, 1u);
+                return v;
             };
-#pragma unroll
-            for (int q = 0; q < REGQ; ++q) {
-                const u32 g = wave + SEG_WAVES * q;
-                if (g < full && gmax[g] >= first_later) apply(g, 0u, 1u, [&]() __attribute__((always_inline)) { return rb[q]; });
+            u32 tv = ticket();
+            for (;;) {
+                const u32 tk = (u32)__builtin_amdgcn_readfirstlane((int)tv);
+                if (tk >= ntk) break;
+                tv = ticket();                          // the next one is on its way while this one is worked on
+                const u32 g = ng - 1u - (tk >> tshift);
+                if (gmax[g] >= first_later)
+                    apply(g, tk & ((1u << tshift) - 1u), 1u << tshift, [&]() __attribute__((always_inline)) {
+                        const u32 s = g * 64 + lane;
+                        if (g < ncache) return lbox[g * 64 + lane];
+                        return s < n ? mbox[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    });
             }
-            for (u32 g = G0 + wave; g < full; g += SEG_WAVES)
-                if (gmax[g] >= first_later) apply(g, 0u, 1u, [&]() __attribute__((always_inline)) { return cached(g); });
-            if (tgroup < ng && gmax[tgroup] >= first_later)
-                apply(tgroup, tpart, tparts, [&]() __attribute__((always_inline)) { return cached(tgroup); });
         }
         if (have_next) {
             bx = nbx;
@@ -1263,11 +1269,10 @@ int nms_batched_impl(const float *pred, int batch, int a, int c, int in_cxcywh, 
     YAMD_REQUIRE(slds <= 160 * 1024, "A=%d needs %zu bytes of LDS for the sweep", a, slds);
     // the sweep's box cache fills what two workgroups per compute unit leave behind the sweep state
     const size_t cache_off = (sweep_lds + 15) & ~(size_t)15;
-    const size_t beyond_regs = ngmax > (size_t)SEG_WAVES ? ngmax - (size_t)SEG_WAVES : ngmax;      // see cbase in the kernel
     size_t cache_groups = 0;
     if (cache_off + 1024 <= 80 * 1024) {
         cache_groups = (80 * 1024 - cache_off) / 1024;
-        if (cache_groups > beyond_regs) cache_groups = beyond_regs;
+        if (cache_groups > ngmax) cache_groups = ngmax;
         if (slds < cache_off + cache_groups * 1024) slds = cache_off + cache_groups * 1024;
     }
     char *ws = (char *)workspace;
