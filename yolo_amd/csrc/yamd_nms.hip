@@ -11,11 +11,11 @@
 //   3. bucket   scatter keys into their class buckets (order inside a bucket is arbitrary).
 //   4. segment  one workgroup per (image, class): bitonic-sort the bucket's keys (keys are unique, so
 //               descending key order IS the stable descending score order), write keys and class-offset
-//               boxes in sorted order, then run the greedy sweep in tiles of 64 boxes: the tile is
-//               resolved with ballots (bit i of a mask = box i), the kept boxes are broadcast through
-//               LDS and every wave clears the later boxes they suppress (one ballot -> one 64-bit word
-//               of the removed-bitmask in LDS per wave step), skipping whole 64-box groups whose
-//               bounding box no kept box touches.
+//               boxes in sorted order, then run the greedy sweep in tiles of 64 boxes: the tile's 64x64
+//               suppression matrix is built by all waves, wave 0 resolves it as a fixed point on 64-bit
+//               masks (bit i = box i), the kept boxes are broadcast through LDS and the waves clear the
+//               later boxes they suppress (one ballot -> one 64-bit word of the removed-bitmask in LDS per
+//               group), skipping whole 64-box groups whose bounding box no kept box touches.
 //               Boxes of different classes never interact: their offset boxes are disjoint because
 //               img_size <= 4096, which is what adding cls*4096 achieves in the reference.
 //   5. gather   kept rows of an image are merged across classes into global descending-score order
@@ -228,13 +228,18 @@ __device__ __forceinline__ float iou_union(float inter, float ia, float ja)
     uni = uni - inter;
     return uni;
 }
-__device__ __forceinline__ void iou_band_test(float inter, float uni, const IouBand &band, bool &gt, bool &open)
+// lanes whose predicate holds, straight from the compare's mask (__ballot takes an int: a select and a second compare)
+__device__ __forceinline__ u64 ballot64(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+// The band test of a whole wave as lane masks (the three compares feed scalar mask arithmetic directly; bools combined
+// per lane would go through a select and a second compare before a ballot, and && / || become branches)
+__device__ __forceinline__ void iou_band_masks(float inter, float uni, const IouBand &band, u64 &gt, u64 &open)
 {
     // both implications divide by uni: they need uni > 0.  Boxes with x2 < x1 or y2 < y1 (an xyxy input may hold them)
     // have negative "areas" and can make uni <= 0 or NaN: such pairs are open as well
-    const bool pos = uni > 0.0f;
-    gt = pos && inter > __fmaf_rn(uni, band.hi, 1e-30f);
-    open = !gt && !(pos && inter < __fmaf_rn(uni, band.lo, -1e-30f));
+    const u64 pos = ballot64(uni > 0.0f);
+    const u64 above = ballot64(inter > __fmaf_rn(uni, band.hi, 1e-30f)), below = ballot64(inter < __fmaf_rn(uni, band.lo, -1e-30f));
+    gt = pos & above;
+    open = ~(pos & (above | below));
 }
 __device__ __forceinline__ bool iou_exact_gt(float inter, float uni, float thr)
 {
@@ -404,12 +409,12 @@ __device__ __forceinline__ T &at32(T *base, u32 i) { return *(T *)((char *)base 
 //     grid cells numbered along a Morton curve) so that 64 consecutive boxes form a compact GROUP with a small
 //     bounding box,
 //  3. greedy sweep in tiles of 64 score-consecutive boxes, two barriers per tile:
-//       B(t)  wave 0 resolves tile t serially on scalar bit masks from the tile's 64x64 suppression matrix
-//             (64 column ballots in LDS) and the removed-bits; the kept boxes go to LDS;
-//       C(t)  every wave takes groups; the kept boxes (one per lane) are first tested against the group's
-//             bounding box with one ballot, and only the few that can intersect it are applied to the
-//             group's boxes (held in registers); results land in the removed-bitmask (one 64-bit word per
-//             group);
+//       B(t)  wave 0 resolves tile t on bit masks: lane j holds row j of the tile's 64x64 suppression matrix (which
+//             earlier boxes of the tile remove box j) and the kept set is iterated to its fixed point; the kept
+//             boxes go to LDS;
+//       C(t)  the waves draw groups by ticket; the kept boxes (one per lane) are first tested against the group's
+//             bounding box with one ballot, and only the few that can intersect it are applied to the group's
+//             boxes; results land in the removed-bitmask (one 64-bit word per group);
 //       A(t+1) in the same interval every wave computes 4 columns of the next tile's suppression matrix.
 //     The bounding-box test only skips pairs whose intersection is exactly empty, so the kept set is
 //     the one the plain greedy loop produces.
@@ -652,7 +657,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
     // `dead`: boxes of the tile that are already removed; a removed box suppresses nothing, its column stays zero
     auto phase_a = [&](u32 t, const float4 bx, const float ar, const u64 dead) __attribute__((always_inline)) {
         const u32 tn = min(64u, n - t * 64);
-        const bool inr = (u32)lane < tn;
+        const u64 valid = tn >= 64u ? ~0ull : (1ull << tn) - 1ull;
         u32 nib = 0u;
 #pragma unroll
         for (int ii = 0; ii < CPW; ++ii) {
@@ -660,11 +665,12 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             if ((u32)i < tn && !((dead >> i) & 1ull)) {
                 const float inter = iou_inter_pos(rl(bx.x, i), rl(bx.y, i), rl(bx.z, i), rl(bx.w, i), bx.x, bx.y, bx.z, bx.w);
                 const float uni = iou_union(inter, rl(ar, i), ar);
-                const bool later = inr && lane > i;
-                bool sup, open;
-                iou_band_test(inter, uni, band, sup, open);
-                if (__ballot(open && later) != 0ull) sup = iou_exact_gt(inter, uni, band.thr);
-                nib |= (sup && later) ? (1u << ii) : 0u;
+                u64 gt, open;
+                iou_band_masks(inter, uni, band, gt, open);
+                const u64 later = valid & ~((2ull << i) - 1ull);          // lanes j > i that hold a box
+                bool sup = (gt >> lane) & 1ull;
+                if (open & later) sup = iou_exact_gt(inter, uni, band.thr);
+                nib |= (sup && ((later >> lane) & 1ull)) ? (1u << ii) : 0u;
             }
         }
         rowb[lane * SEG_WAVES + wave] = (unsigned char)nib;
@@ -691,7 +697,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
     u32 nkept = 0;
     for (u32 t = 0; t < ng; ++t) {
         const u32 tn = min(64u, n - t * 64);
-        // ---- B(t): serial resolve on wave 0
+        // ---- B(t): tile resolve on wave 0
         if (wave == 0) {
             const bool inr = (u32)lane < tn;
             const bool alive = inr && !((rem[sp_cur >> 6] >> (sp_cur & 63)) & 1ull);
@@ -700,10 +706,10 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             // greedy pass as a fixed point: box j is kept iff it is alive and no KEPT box i < j removes it.  A row only
             // holds bits i < j, so position j is final once positions < j are: every round settles at least one more
             // position, the fixed point is unique, and it is what the serial loop over i produces.
-            u64 kept = __ballot(alive), prev;
+            u64 kept = ballot64(alive), prev;
             do {
                 prev = kept;
-                kept = __ballot(alive && ((rlo & (u32)prev) | (rhi & (u32)(prev >> 32))) == 0u);
+                kept = ballot64(alive && ((rlo & (u32)prev) | (rhi & (u32)(prev >> 32))) == 0u);
             } while (kept != prev);
             if ((kept >> lane) & 1ull) {
                 const u32 pos = (u32)__popcll(kept & ((1ull << lane) - 1ull));
@@ -748,7 +754,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             auto apply = [&](const u32 g, const u32 part, const u32 parts, auto boxes) __attribute__((always_inline)) {
                 const float4 bb = gbb[g];
                 const bool ov = (u32)lane < nk && kx.z > bb.x && kx.x < bb.z && kx.w > bb.y && kx.y < bb.w;
-                u64 rel = __ballot(ov);
+                u64 rel = ballot64(ov);
                 if (parts > 1u) {
                     // this wave's share of the relevant kept boxes: number part, part + parts, ... (picked here, on the
                     // scalar unit, so that the loop over them below stays as it is)
@@ -764,7 +770,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
                 PH_WAVE_COUNT(11, 1);
                 if (rel == 0ull) return;
                 const bool todo = g * 64 + lane < n && !((rem[g] >> lane) & 1ull);
-                if (__ballot(todo) == 0ull) return;
+                if (ballot64(todo) == 0ull) return;
                 const float4 jx = boxes();
                 const float ja = (jx.z - jx.x) * (jx.w - jx.y);
                 PH_WAVE_COUNT(12, 1);
@@ -772,23 +778,24 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
                 // the kept boxes come out of the lanes' registers (lane k holds kept box k); pairs the band test leaves
                 // open are rare and wait in `redo` for the division, so that the loop has no branch but its own
                 u64 supm = 0ull, redo = 0ull;
+                const u64 todom = ballot64(todo);
                 while (rel) {
                     const int k = __ffsll((long long)rel) - 1;
                     rel &= rel - 1ull;
                     const float inter = iou_inter_pos(rl(kx.x, k), rl(kx.y, k), rl(kx.z, k), rl(kx.w, k), jx.x, jx.y, jx.z, jx.w);
                     const float uni = iou_union(inter, rl(kar, k), ja);
-                    bool gt, open;
-                    iou_band_test(inter, uni, band, gt, open);
-                    supm |= __ballot(gt);
-                    redo |= __ballot(open && todo) != 0ull ? 1ull << k : 0ull;
+                    u64 gt, open;
+                    iou_band_masks(inter, uni, band, gt, open);
+                    supm |= gt;
+                    redo |= (open & todom) != 0ull ? 1ull << k : 0ull;
                 }
                 while (redo) {
                     const int k = __ffsll((long long)redo) - 1;
                     redo &= redo - 1ull;
                     const float inter = iou_inter_pos(rl(kx.x, k), rl(kx.y, k), rl(kx.z, k), rl(kx.w, k), jx.x, jx.y, jx.z, jx.w);
-                    supm |= __ballot(iou_exact_gt(inter, iou_union(inter, rl(kar, k), ja), band.thr));
+                    supm |= ballot64(iou_exact_gt(inter, iou_union(inter, rl(kar, k), ja), band.thr));
                 }
-                const u64 sm = supm & __ballot(todo);
+                const u64 sm = supm & todom;
                 if (lane == 0 && sm) atomicOr(&rem[g], sm);
             };
             auto ticket = [&]() __attribute__((always_inline)) {
@@ -817,7 +824,7 @@ __global__ __launch_bounds__(SEG_THREADS, MIN_WAVES) void nms_segment_kernel(Nms
             key_cur = nkey;
             // what earlier tiles (and the part of this one's phase C that has landed) removed of the next tile
             const bool gone = (t + 1) * 64 + lane < n && ((rem[nsp >> 6] >> (nsp & 63)) & 1ull);
-            phase_a(t + 1, bx, ar, __ballot(gone));
+            phase_a(t + 1, bx, ar, ballot64(gone));
         }
         PH(6);
         __syncthreads();
