@@ -317,12 +317,31 @@ def realistic_regime(args, p, model, images, sink, steps=5, target=300.0):
         model.load_state_dict(sd)
 
     sub = images[:min(8, images.shape[0])]
-    best = None
-    for shift in (-6.0, -4.0, -3.0, -2.0, -1.0, 0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0):
+
+    def count(shift):
         load(shift)
-        cand, _ = candidate_stats(p, model.decode_predict(model.raw_heads(sub)))
-        if best is None or abs(np.log(max(cand, 1e-3) / target)) < abs(np.log(max(best[1], 1e-3) / target)):
-            best = (shift, cand)
+        return candidate_stats(p, model.decode_predict(model.raw_heads(sub)))[0]
+
+    def miss(cand):
+        return abs(np.log(max(cand, 1e-3) / target))
+
+    grid = (-6.0, -4.0, -3.0, -2.0, -1.0, 0.0, 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0)
+    counts = [count(sh) for sh in grid]
+    best = min(zip(grid, counts), key=lambda t: miss(t[1]))
+    # the count falls with the shift; where two grid points straddle the target (single-class heads go from every
+    # anchor to none within one unit), halve the interval a few times
+    for lo, hi, clo, chi in zip(grid[:-1], grid[1:], counts[:-1], counts[1:]):
+        if clo >= target >= chi and miss(best[1]) > 0.3:
+            for _ in range(6):
+                mid = 0.5 * (lo + hi)
+                cm = count(mid)
+                if miss(cm) < miss(best[1]):
+                    best = (mid, cm)
+                if cm >= target:
+                    lo = mid
+                else:
+                    hi = mid
+            break
     load(best[0])
     for _ in range(2):
         step(model, images, sink)
