@@ -36,7 +36,7 @@ def iou_gt(k, bx, thr):
     with np.errstate(divide="ignore", invalid="ignore"):
         return inter / uni > thr
 
-def sweep(box, thr, hi, regroup_every=0, classes=2):
+def sweep(box, thr, hi, regroup_every=0, classes=2, regroup_at=()):
     """box: (n,4) xyxy in descending score order.  Returns (kept mask, counts)."""
     n = box.shape[0]
     removed = np.zeros(n, bool)
@@ -49,7 +49,7 @@ def sweep(box, thr, hi, regroup_every=0, classes=2):
     nt = (n + 63) // 64
     cnt = dict(c_steps=0, bb_tests=0, a_cols=0, lanes_used=0, regroups=0)
     for t in range(nt):
-        if regroup_every and t and t % regroup_every == 0:
+        if (regroup_every and t and t % regroup_every == 0) or t in regroup_at:
             alive_later = np.nonzero(~removed & (np.arange(n) >= t * 64))[0]
             groups = group(alive_later)
             cnt["regroups"] += 1
@@ -111,9 +111,17 @@ def main():
         order = idx[np.argsort(-score[idx], kind="stable")]
         box = allb[order]
         base = None
-        for tag, kw in (("as built", {}), ("regroup / 8 tiles", dict(regroup_every=8)), ("regroup / 4 tiles", dict(regroup_every=4)),
-                        ("regroup / 2 tiles", dict(regroup_every=2)), ("4 size classes", dict(classes=4)),
-                        ("4 classes + regroup / 4", dict(classes=4, regroup_every=4))):
+        nt = (len(order) + 63) // 64
+        variants = [("as built", {}), ("regroup / 8 tiles", dict(regroup_every=8)), ("regroup / 4 tiles", dict(regroup_every=4)),
+                    ("regroup / 2 tiles", dict(regroup_every=2)), ("4 size classes", dict(classes=4)),
+                    ("4 classes + regroup / 4", dict(classes=4, regroup_every=4))]
+        if os.environ.get("SIM_SCHEDULES"):
+            variants = [("as built", {}), ("every 8", dict(regroup_every=8)), ("every 16", dict(regroup_every=16)),
+                        ("at 1/4, 1/2, 3/4", dict(regroup_at=(nt // 4, nt // 2, 3 * nt // 4))),
+                        ("at 1/8, 1/4, 1/2", dict(regroup_at=(nt // 8, nt // 4, nt // 2))),
+                        ("at 1/6, 1/3, 2/3", dict(regroup_at=(nt // 6, nt // 3, 2 * nt // 3))),
+                        ("at 1/3, 2/3", dict(regroup_at=(nt // 3, 2 * nt // 3))), ("at 1/2", dict(regroup_at=(nt // 2,)))]
+        for tag, kw in variants:
             kept, cnt = sweep(box, float(p.nms_threshold), hi, **kw)
             if base is None:
                 base = kept
