@@ -220,9 +220,21 @@ struct FusedGeom {
     }
 };
 
+// Focus stems (KS == 6): the image patch under a tile is staged in space-to-depth form, the way the reference's Focus
+// layer slices it: pixel (Y, X) of the half-resolution image holds the 12 channels q * 3 + ch = image pixel
+// (2Y + dy, 2X + dx) of channel ch, q = dy + 2 dx, as 32 bytes (channels 12 - 15 zero).  The 6 x 6 stride-2 conv is the
+// 3 x 3 pad-1 conv on that image, so a k-step of the stem is one tap and a lane's B operand one 16-byte read (channels
+// 8g .. 8g + 7 of its pixel's neighbour) instead of four 4-byte gathers with their address arithmetic; 9 k-steps instead
+// of 7.  The two 16-byte halves of a pixel swap places in every second run of 8 columns, which spreads the reads of 16
+// neighbouring pixels over all banks.
+constexpr int F_SR = F_IR + 2, F_SC = F_IC + 2;             // half-resolution pixels under the tile's stem pixels
+constexpr int F_SPIX = F_SR * F_SC;
+constexpr int F_STAPS = 9;
+__device__ __forceinline__ int s2d_offset(int y, int x, int half) { return (y * F_SC + x) * 32 + ((half ^ ((x >> 3) & 1)) << 4); }
+
 struct FusedParams {
     const float *img;
-    const bf16x8 *w1;      // stem weights, [kstep][ncol][lane] fragments
+    const bf16x8 *w1;      // stem weights, [kstep][ncol][lane] fragments (Focus: the tap-major fragments behind them)
     const float *b1;
     const char *w2;        // second conv, [tap][kstep][ncol] fragments of 1 KB
     const float *b2;
@@ -242,7 +254,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
     constexpr int KS2 = C1 / 16;                           // k-steps per tap of the second conv
     constexpr int RS2 = C1 * 2 + 16;                       // bytes per stem pixel in LDS (padded: conflict-free 16-byte reads)
     constexpr int RSO = NREP2 * 64 + 16;                   // bytes per pixel of the output staging tile
-    constexpr int PATCH_BYTES = ((G::PATCH + 8) * 2 + 15) / 16 * 16;
+    constexpr bool S2D = KS == 6;
+    constexpr int PATCH_BYTES = S2D ? F_SPIX * 32 : ((G::PATCH + 8) * 2 + 15) / 16 * 16;
     constexpr int STAGE_BYTES = 64 * RSO;
     constexpr int A_BYTES = PATCH_BYTES > STAGE_BYTES ? PATCH_BYTES : STAGE_BYTES;   // patch, later the output tile
     constexpr int I_BYTES = F_IR * F_CROW * RS2;
@@ -258,11 +271,12 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
     // second-conv weights: resident in LDS for all tiles of this workgroup
     for (int q = tid; q < W2_BYTES / 16; q += 256) *(u32x4 *)(w2s + q * 16) = *(const u32x4 *)(p.w2 + q * 16);
     // stem weights: one A fragment per (k step, 32-cout column), in registers
-    bf16x8 wf[G::KSTEPS][NREP1];
+    constexpr int KST = S2D ? F_STAPS : G::KSTEPS;
+    bf16x8 wf[KST][NREP1];
 #pragma unroll
-    for (int ks = 0; ks < G::KSTEPS; ++ks)
+    for (int ks = 0; ks < KST; ++ks)
 #pragma unroll
-        for (int n = 0; n < NREP1; ++n) wf[ks][n] = p.w1[(ks * NREP1 + n) * 64 + lane];
+        for (int n = 0; n < NREP1; ++n) wf[ks][n] = p.w1[((S2D ? G::KSTEPS : 0) * NREP1 + ks * NREP1 + n) * 64 + lane];
 
     // biases in registers for all tiles
     f32x4 bias1[NREP1][4], bias2[NQ][4];
@@ -278,16 +292,25 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
     const int act1 = ACTK >= 0 ? ACTK : p.act1, act2 = ACTK >= 0 ? ACTK : p.act2;
 
     // The patch is loaded two columns at a time: its first column is even in the image (XO below) and so is its width,
-    // so a pair is 8-byte aligned and lies inside the image or outside it as a whole.
-    constexpr int NE = (G::PATCH / 2 + 255) / 256;
+    // so a pair is 8-byte aligned and lies inside the image or outside it as a whole.  Focus form: a thread takes whole
+    // half-resolution pixels (2 rows x 2 columns x 3 channels = six pairs each), which lie inside or outside as a whole.
+    constexpr int NE = S2D ? 6 * ((F_SPIX + 255) / 256) : (G::PATCH / 2 + 255) / 256;
     f32x2 pv[NE];
-    // pair of this thread -> (channel, row, first column), the same for every tile
-    int prc[NE];
+    // pair of this thread -> (channel, row, first column), the same for every tile (Focus: pixel -> (row, column))
+    int prc[S2D ? NE / 6 : NE];
+    if constexpr (S2D) {
 #pragma unroll
-    for (int u = 0; u < NE; ++u) {
-        const int e = 2 * min(tid + u * 256, G::PATCH / 2 - 1);
-        const int c = e % G::CW, rr = e / G::CW;
-        prc[u] = ((rr / G::R) << 20) | ((rr % G::R) << 10) | c;
+        for (int u = 0; u < NE / 6; ++u) {
+            const int e = min(tid + u * 256, F_SPIX - 1);
+            prc[u] = ((e / F_SC) << 10) | (e % F_SC);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int e = 2 * min(tid + u * 256, G::PATCH / 2 - 1);
+            const int c = e % G::CW, rr = e / G::CW;
+            prc[u] = ((rr / G::R) << 20) | ((rr % G::R) << 10) | c;
+        }
     }
     // fp32 patch of tile `t` into registers: clamped addresses and a select, no branch; one memory latency per tile
     auto load_patch = [&](int t) __attribute__((always_inline)) {
@@ -295,14 +318,31 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
         t /= p.tiles_x;
         const int ty = t % p.tiles_y;
         const long long b = t / p.tiles_y;
-        const int ih0 = (2 * ty * F_TH - 1) * S - G::PAD, iw0 = (2 * tx * F_TW - 1) * S - G::PAD - G::XO;
         const float *img = p.img + b * 3 * (long long)p.H * p.W;
+        if constexpr (S2D) {
+            const int y0 = 2 * ty * F_TH - 2, x0 = 2 * tx * F_TW - 2;      // half-resolution pixel (0, 0) of the patch
 #pragma unroll
-        for (int u = 0; u < NE; ++u) {
-            const int ch = prc[u] >> 20, ih = ih0 + ((prc[u] >> 10) & 1023), iw = iw0 + (prc[u] & 1023);
-            const bool inb = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-            const f32x2 v = *(const f32x2 *)(img + (ch * p.H + min(max(ih, 0), p.H - 1)) * p.W + min(max(iw, 0), p.W - 2));
-            pv[u] = inb ? v : f32x2{0.0f, 0.0f};
+            for (int u = 0; u < NE / 6; ++u) {
+                const int sy = y0 + (prc[u] >> 10), sx = x0 + (prc[u] & 1023);
+                const bool inb = sy >= 0 && 2 * sy < p.H && sx >= 0 && 2 * sx < p.W;
+                const float *src = img + 2 * min(max(sy, 0), p.H / 2 - 1) * p.W + 2 * min(max(sx, 0), p.W / 2 - 1);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy) {
+                        const f32x2 v = *(const f32x2 *)(src + (ch * p.H + dy) * p.W);
+                        pv[u * 6 + ch * 2 + dy] = inb ? v : f32x2{0.0f, 0.0f};
+                    }
+            }
+        } else {
+            const int ih0 = (2 * ty * F_TH - 1) * S - G::PAD, iw0 = (2 * tx * F_TW - 1) * S - G::PAD - G::XO;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int ch = prc[u] >> 20, ih = ih0 + ((prc[u] >> 10) & 1023), iw = iw0 + (prc[u] & 1023);
+                const bool inb = ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+                const f32x2 v = *(const f32x2 *)(img + (ch * p.H + min(max(ih, 0), p.H - 1)) * p.W + min(max(iw, 0), p.W - 2));
+                pv[u] = inb ? v : f32x2{0.0f, 0.0f};
+            }
         }
     };
 
@@ -329,17 +369,37 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
         const int oh0 = ty * F_TH, ow0 = tx * F_TW;
         const int ir0 = 2 * oh0 - 1, ic0 = 2 * ow0 - 1;      // first stem pixel under the tile
 
+        if constexpr (S2D) {
 #pragma unroll
-        for (int u = 0; u < NE; ++u) {
-            const int e = tid + u * 256;
-            if (e < G::PATCH / 2) {
-                bf16x2 o;
-                o[0] = (__bf16)pv[u][0];
-                o[1] = (__bf16)pv[u][1];
-                *(bf16x2 *)(patch + 2 * e) = o;
+            for (int u = 0; u < NE / 6; ++u) {
+                if (tid + u * 256 < F_SPIX) {
+                    // channel q * 3 + ch, q = dy + 2 dx, from pv[ch * 2 + dy][dx]
+                    bf16x8 lo, hi;
+#pragma unroll
+                    for (int f = 0; f < 16; ++f) {
+                        const int q = f / 3, ch = f % 3;
+                        const __bf16 v = f < 12 ? (__bf16)pv[u * 6 + ch * 2 + (q & 1)][q >> 1] : (__bf16)0.0f;
+                        if (f < 8) lo[f] = v;
+                        else hi[f - 8] = v;
+                    }
+                    const int y = prc[u] >> 10, x = prc[u] & 1023;
+                    *(bf16x8 *)((char *)patch + s2d_offset(y, x, 0)) = lo;
+                    *(bf16x8 *)((char *)patch + s2d_offset(y, x, 1)) = hi;
+                }
             }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {
+                const int e = tid + u * 256;
+                if (e < G::PATCH / 2) {
+                    bf16x2 o;
+                    o[0] = (__bf16)pv[u][0];
+                    o[1] = (__bf16)pv[u][1];
+                    *(bf16x2 *)(patch + 2 * e) = o;
+                }
+            }
+            if (tid < 8) patch[G::PATCH + tid] = (__bf16)0.0f;
         }
-        if (tid < 8) patch[G::PATCH + tid] = (__bf16)0.0f;
         if (tid == 0) *s_next = ticket;
         __syncthreads();
         const int next = *s_next;
@@ -350,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
         for (int f = wave; f < F_IFRAG; f += 4) {
             const int s_raw = f * 32 + c32, s = min(s_raw, F_IPIX - 1);
             const int r = s / F_IC, c = s - r * F_IC;
-            const int base = (r * S) * G::CW + c * S + G::XO;  // patch origin of this lane's stem pixel
+            [[maybe_unused]] const int base = (r * S) * G::CW + c * S + G::XO;  // patch origin of this lane's stem pixel
             f32x16 acc[NREP1];
 #pragma unroll
             for (int n = 0; n < NREP1; ++n)
@@ -359,18 +419,11 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[n][4 * i + j] = bias1[n][i][j];
 #pragma unroll
-            for (int ks = 0; ks < G::KSTEPS; ++ks) {
+            for (int ks = 0; ks < KST; ++ks) {
                 bf16x8 a;
-                if constexpr (KS == 6) {
-                    // (k, k+1) for even k are neighbours in a patch row; row pitch, stride and origin are even: one 32-bit read
-                    u32x4 av;
-#pragma unroll
-                    for (int j = 0; j < 8; j += 2) {
-                        const int o0 = G::off(ks * 16 + j), o1 = G::off(ks * 16 + 8 + j);
-                        const int idx = g ? (o1 < 0 ? G::PATCH : base + o1) : (o0 < 0 ? G::PATCH : base + o0);
-                        av[j / 2] = *(const unsigned *)(patch + idx);
-                    }
-                    a = __builtin_bit_cast(bf16x8, av);
+                if constexpr (S2D) {
+                    // k-step = tap (ks / 3, ks % 3) of the 3x3 conv on the half-resolution image
+                    a = *(const bf16x8 *)((const char *)patch + s2d_offset(r + ks / 3, c + ks % 3, g));
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
@@ -467,7 +520,7 @@ int launch_stem_conv2_act(const FusedParams &p, hipStream_t st)
 {
     using G = FusedGeom<KS, S>;
     constexpr int C1 = NREP1 * 32, RS2 = C1 * 2 + 16, RSO = NREP2 * 64 + 16;
-    constexpr int PATCH_BYTES = ((G::PATCH + 8) * 2 + 15) / 16 * 16, STAGE_BYTES = 64 * RSO;
+    constexpr int PATCH_BYTES = KS == 6 ? F_SPIX * 32 : ((G::PATCH + 8) * 2 + 15) / 16 * 16, STAGE_BYTES = 64 * RSO;
     constexpr int A_BYTES = PATCH_BYTES > STAGE_BYTES ? PATCH_BYTES : STAGE_BYTES;
     constexpr size_t LDS = (size_t)A_BYTES + (size_t)F_IR * F_CROW * RS2 + (size_t)9 * (C1 / 16) * NREP2 * 1024 + 16;
     static_assert(LDS <= 160 * 1024, "fused stem tile does not fit LDS");
@@ -573,7 +626,8 @@ extern "C" int64_t yamd_stem_packed_elems(int mode, int cout)
     int ks, s;
     if (!stem_mode(mode, ks, s) || cout <= 0 || cout > 64) return 0;
     const int ksteps = (3 * ks * ks + 15) / 16, nrep = cout <= 32 ? 1 : 2;
-    return (int64_t)ksteps * nrep * 64 * 8;
+    // Focus: the 7 k-steps in image order (yamd_stem_conv), then 9 tap-major k-steps (the fused kernel's space-to-depth form)
+    return (int64_t)(ksteps + (mode == YAMD_STEM_FOCUS ? F_STAPS : 0)) * nrep * 64 * 8;
 }
 
 extern "C" int yamd_stem_pack_weights(int mode, const float *w, const float *bias, int cout, void *w_packed, float *bias_packed)
@@ -603,6 +657,18 @@ extern "C" int yamd_stem_pack_weights(int mode, const float *w, const float *bia
                     }
                     out[(((size_t)kk * nrep + n) * 64 + lane) * 8 + j] = (__bf16)v;
                 }
+    if (mode == YAMD_STEM_FOCUS) {
+        // k-step = tap of the reference's 3x3 conv on the 12 Focus channels, k within it = Focus channel (12 .. 15 zero)
+        out += (size_t)ksteps * nrep * 64 * 8;
+        for (int tap = 0; tap < F_STAPS; ++tap)
+            for (int n = 0; n < nrep; ++n)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = n * 32 + (lane & 31), f = (lane >> 5) * 8 + j;
+                        const float v = (co < cout && f < 12) ? w[((size_t)co * 12 + f) * 9 + tap] : 0.0f;
+                        out[(((size_t)tap * nrep + n) * 64 + lane) * 8 + j] = (__bf16)v;
+                    }
+    }
     for (int c = 0; c < nrep * 32; ++c) bias_packed[c] = (bias && c < cout) ? bias[c] : 0.0f;
     return YAMD_OK;
 }
