@@ -406,51 +406,103 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
         if (tid == 0) ticket = (int)gridDim.x + (int)atomicAdd(p.ticket, 1u);
         if (next < p.total_tiles) load_patch(next);      // in flight during this tile's MFMAs
 
-        // ---- stem on the 9 x 33 pixels under the tile, 32 at a time
-        for (int f = wave; f < F_IFRAG; f += 4) {
-            const int s_raw = f * 32 + c32, s = min(s_raw, F_IPIX - 1);
-            const int r = s / F_IC, c = s - r * F_IC;
-            [[maybe_unused]] const int base = (r * S) * G::CW + c * S + G::XO;  // patch origin of this lane's stem pixel
-            f32x16 acc[NREP1];
+        // ---- stem on the 9 x 33 pixels under the tile, 32 at a time; a wave takes its first two fragments together (their
+        // operand reads, MFMAs and activations in one block of code, so that one's latencies lie under the other's work)
+        auto stem_frags = [&](auto nf_tag, const int f0) __attribute__((always_inline)) {
+            constexpr int NF = decltype(nf_tag)::value;
+            int s_raw[NF], r[NF], c[NF];
+            [[maybe_unused]] int base[NF];
+            f32x16 acc[NF][NREP1];
 #pragma unroll
-            for (int n = 0; n < NREP1; ++n)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[n][4 * i + j] = bias1[n][i][j];
-#pragma unroll
-            for (int ks = 0; ks < KST; ++ks) {
-                bf16x8 a;
-                if constexpr (S2D) {
-                    // k-step = tap (ks / 3, ks % 3) of the 3x3 conv on the half-resolution image
-                    a = *(const bf16x8 *)((const char *)patch + s2d_offset(r + ks / 3, c + ks % 3, g));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int o0 = G::off(ks * 16 + j), o1 = G::off(ks * 16 + 8 + j);
-                        const int idx = g ? (o1 < 0 ? G::PATCH : base + o1) : (o0 < 0 ? G::PATCH : base + o0);
-                        a[j] = patch[idx];
-                    }
-                }
-#pragma unroll
-                for (int n = 0; n < NREP1; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][n], a, acc[n], 0, 0, 0);
-            }
-            // activation, bf16, into the stem image; pixels outside the stem's output are the second conv's padding
-            const int ir = ir0 + r, ic = ic0 + c;
-            const bool real = ir >= 0 && ir < p.H1 && ic >= 0 && ic < p.W1;
-            if (s_raw < F_IPIX) {
-                char *dst = inter + (r * F_CROW + (c & 1) * F_HALF + (c >> 1)) * RS2;
+            for (int u = 0; u < NF; ++u) {
+                s_raw[u] = (f0 + 4 * u) * 32 + c32;
+                const int sp = min(s_raw[u], F_IPIX - 1);
+                r[u] = sp / F_IC;
+                c[u] = sp - r[u] * F_IC;
+                base[u] = (r[u] * S) * G::CW + c[u] * S + G::XO;   // patch origin of this lane's stem pixel
 #pragma unroll
                 for (int n = 0; n < NREP1; ++n)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        bf16x4 o;
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = (__bf16)(real ? apply_act(acc[n][4 * i + j], act1) : 0.0f);
-                        *(bf16x4 *)(dst + (n * 32 + 8 * i + 4 * g) * 2) = o;
-                    }
+                        for (int j = 0; j < 4; ++j) acc[u][n][4 * i + j] = bias1[n][i][j];
             }
+            if constexpr (S2D && NREP1 == 1) {
+                // a row of taps is requested while the MFMAs of the row before run (the compiler, left alone, asks for one
+                // k-step at a time and waits for it: nine LDS latencies in a row); two register buffers
+                bf16x8 a[2][NF][3];
+                auto fetch = [&](const int row, const int buf) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int u = 0; u < NF; ++u)   // k-step = tap (row, kx) of the 3x3 conv on the half-resolution image
+                            a[buf][u][kx] = *(const bf16x8 *)((const char *)patch + s2d_offset(r[u] + row, c[u] + kx, g));
+                };
+                fetch(0, 0);
+#pragma unroll
+                for (int row = 0; row < 3; ++row) {
+                    if (row < 2) fetch(row + 1, (row + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int u = 0; u < NF; ++u)
+#pragma unroll
+                            for (int n = 0; n < NREP1; ++n)
+                                acc[u][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[row * 3 + kx][n], a[row & 1][u][kx], acc[u][n], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks) {
+                    bf16x8 a[NF];
+#pragma unroll
+                    for (int u = 0; u < NF; ++u) {
+                        if constexpr (S2D) {
+                            a[u] = *(const bf16x8 *)((const char *)patch + s2d_offset(r[u] + ks / 3, c[u] + ks % 3, g));
+                            continue;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int o0 = G::off(ks * 16 + j), o1 = G::off(ks * 16 + 8 + j);
+                            const int idx = g ? (o1 < 0 ? G::PATCH : base[u] + o1) : (o0 < 0 ? G::PATCH : base[u] + o0);
+                            a[u][j] = patch[idx];
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < NF; ++u)
+#pragma unroll
+                        for (int n = 0; n < NREP1; ++n)
+                            acc[u][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks][n], a[u], acc[u][n], 0, 0, 0);
+                }
+            }
+            // activation, bf16, into the stem image; pixels outside the stem's output are the second conv's padding
+#pragma unroll
+            for (int u = 0; u < NF; ++u) {
+                const int ir = ir0 + r[u], ic = ic0 + c[u];
+                const bool real = ir >= 0 && ir < p.H1 && ic >= 0 && ic < p.W1;
+                if (s_raw[u] < F_IPIX) {
+                    char *dst = inter + (r[u] * F_CROW + (c[u] & 1) * F_HALF + (c[u] >> 1)) * RS2;
+#pragma unroll
+                    for (int n = 0; n < NREP1; ++n)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            bf16x4 o;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) o[j] = (__bf16)(real ? apply_act(acc[u][n][4 * i + j], act1) : 0.0f);
+                            *(bf16x4 *)(dst + (n * 32 + 8 * i + 4 * g) * 2) = o;
+                        }
+                }
+            }
+        };
+        static_assert(F_IFRAG > 8 && F_IFRAG <= 12, "a wave's fragments: two together, at most one more");
+        if constexpr (NREP1 == 1) {
+            stem_frags(std::integral_constant<int, 2>{}, wave);
+        } else {                                          // 64 stem channels: two fragments' accumulators do not fit
+            stem_frags(std::integral_constant<int, 1>{}, wave);
+            stem_frags(std::integral_constant<int, 1>{}, wave + 4);
         }
+        if (wave + 8 < F_IFRAG) stem_frags(std::integral_constant<int, 1>{}, wave + 8);
         __syncthreads();
 
         // ---- second conv: 3x3 stride 2 from the stem image
@@ -461,20 +513,38 @@ __global__ __launch_bounds__(256, 2) void stem_conv2_kernel(FusedParams p)
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc2[q][4 * i + j] = bias2[q][i][j];
+        // operands are requested a group of k-steps ahead of the MFMAs that use them (two register buffers)
+        constexpr int NS = 9 * KS2, GS = (NQ == 1 && NREP1 == 1) ? 3 : 1, NG = (NS + GS - 1) / GS;
+        bf16x8 pa[2][GS], pw[2][GS][NQ];
+        auto fetch = [&](const int grp, const int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
-            const int tapoff = (ky * F_CROW + (kx & 1) * F_HALF + (kx >> 1)) * RS2;
+            for (int i = 0; i < GS; ++i) {
+                const int st = grp * GS + i;
+                if (st < NS) {
+                    const int tap = st / KS2, ks = st % KS2, ky = tap / 3, kx = tap % 3;
+                    const int tapoff = (ky * F_CROW + (kx & 1) * F_HALF + (kx >> 1)) * RS2;
+                    pa[buf][i] = *(const bf16x8 *)(inter + pixbase + tapoff + ks * 32);
 #pragma unroll
-            for (int ks = 0; ks < KS2; ++ks) {
-                const bf16x8 a = *(const bf16x8 *)(inter + pixbase + tapoff + ks * 32);
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const int n = min(wn + 2 * q, NREP2 - 1);
-                    const bf16x8 wv = *(const bf16x8 *)(w2s + ((tap * KS2 + ks) * NREP2 + n) * 1024 + lane * 16);
-                    acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, a, acc2[q], 0, 0, 0);
+                    for (int q = 0; q < NQ; ++q) {
+                        const int n = min(wn + 2 * q, NREP2 - 1);
+                        pw[buf][i][q] = *(const bf16x8 *)(w2s + ((tap * KS2 + ks) * NREP2 + n) * 1024 + lane * 16);
+                    }
                 }
             }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int grp = 0; grp < NG; ++grp) {
+            if (grp + 1 < NG) fetch(grp + 1, (grp + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < GS; ++i)
+                if (grp * GS + i < NS) {
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        acc2[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pw[grp & 1][i][q], pa[grp & 1][i], acc2[q], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- output tile through LDS (the patch is dead since the last barrier), then whole pixel rows to memory
         char *stage = smem;
