@@ -41,7 +41,9 @@ struct StemParams {
     int H, W, Hout, Wout, Cout, y_cs, act, tiles_x, tiles_y;
 };
 
-template <int KS, int S, int NREP>
+// ACTK >= 0: the activation is that kind, fixed at compile time; ACTK < 0: it is looked up per value (a chain of scalar
+// compares and branches for every four outputs: 351 branches in the 3x3 form)
+template <int KS, int S, int NREP, int ACTK>
 __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p)
 {
     using G = StemGeom<KS, S>;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p)
             for (int i = 0; i < 4; ++i) {
                 bf16x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (__bf16)apply_act(acc[m][n][4 * i + j], p.act);
+                for (int j = 0; j < 4; ++j) o[j] = (__bf16)apply_act(acc[m][n][4 * i + j], ACTK >= 0 ? ACTK : p.act);
                 *(bf16x4 *)(wreg + c32 * RSO + (n * 32 + 8 * i + 4 * g) * 2) = o;
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -168,8 +170,18 @@ int launch_stem(const StemParams &p, int batch, hipStream_t st)
 {
     const long long grid = (long long)batch * p.tiles_y * p.tiles_x;
     YAMD_REQUIRE(grid > 0 && grid < (1ll << 31), "stem grid out of range");
-    if (p.Cout <= 32) hipLaunchKernelGGL((stem_conv_kernel<KS, S, 1>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((stem_conv_kernel<KS, S, 2>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    auto launch = [&](auto actk) {
+        constexpr int A = decltype(actk)::value;
+        if (p.Cout <= 32) hipLaunchKernelGGL((stem_conv_kernel<KS, S, 1, A>), dim3((unsigned)grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((stem_conv_kernel<KS, S, 2, A>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    };
+    switch (p.act) {
+    case YAMD_ACT_SILU: launch(std::integral_constant<int, YAMD_ACT_SILU>{}); break;
+    case YAMD_ACT_LEAKY: launch(std::integral_constant<int, YAMD_ACT_LEAKY>{}); break;
+    case YAMD_ACT_RELU: launch(std::integral_constant<int, YAMD_ACT_RELU>{}); break;
+    case YAMD_ACT_MISH: launch(std::integral_constant<int, YAMD_ACT_MISH>{}); break;
+    default: launch(std::integral_constant<int, -1>{}); break;
+    }
     YAMD_LAUNCH_CHECK();
     return YAMD_OK;
 }
