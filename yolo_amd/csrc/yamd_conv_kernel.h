@@ -399,8 +399,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
             // channels of one pixel (Cout*4 contiguous bytes) with consecutive lanes instead of one pixel per lane
             constexpr int RSF = NREP * 128 + 16;       // bytes per pixel row of the staging tile
             char *wreg = epi_lds + wave * (32 * RSF);
-    #pragma unroll
-            for (int m = 0; m < MREP; ++m) {
+            // the fragment's values into the staging tile, with the activation a compile-time constant of the code that runs
+            // (one uniform branch per fragment: looked up per value it is a chain of compares and branches for every one)
+            auto stage_fragment = [&](auto ac, const int m) __attribute__((always_inline)) {
+                constexpr int A = decltype(ac)::value;
     #pragma unroll
                 for (int n = 0; n < NREP; ++n) {
     #pragma unroll
@@ -408,8 +410,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && STAGES == 1) ? 2 : 1) void con
                         const int cl = n * 32 + 8 * i + 4 * g;
                         f32x4 v;
     #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = apply_act(acc[m][n][4 * i + j], p.act);
+                        for (int j = 0; j < 4; ++j) v[j] = apply_act(acc[m][n][4 * i + j], A);
                         *(f32x4 *)(wreg + c32 * RSF + cl * 4) = v;
+                    }
+                }
+            };
+    #pragma unroll
+            for (int m = 0; m < MREP; ++m) {
+                if constexpr (ACTK >= 0) {
+                    stage_fragment(std::integral_constant<int, ACTK>{}, m);
+                } else {
+                    switch (p.act) {
+                    case YAMD_ACT_SILU: stage_fragment(std::integral_constant<int, YAMD_ACT_SILU>{}, m); break;
+                    case YAMD_ACT_LEAKY: stage_fragment(std::integral_constant<int, YAMD_ACT_LEAKY>{}, m); break;
+                    case YAMD_ACT_MISH: stage_fragment(std::integral_constant<int, YAMD_ACT_MISH>{}, m); break;
+                    case YAMD_ACT_RELU: stage_fragment(std::integral_constant<int, YAMD_ACT_RELU>{}, m); break;
+                    default: stage_fragment(std::integral_constant<int, YAMD_ACT_NONE>{}, m); break;
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
