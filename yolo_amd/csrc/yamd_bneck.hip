@@ -324,9 +324,17 @@ template <int CI, int CM, int CO, int MREP, int NW>
 int launch_bneck_shape(const BneckParams &p, int batch, hipStream_t st)
 {
     const int tw = pick_tw(p.W);
+    // the activation kinds the reference's residual units use are compile-time constants of their kernels (looked up per
+    // value the activation is a chain of compares and branches: 1 750 branches in the 64-channel form)
     if (p.act == YAMD_ACT_SILU)
         return tw == 16 ? launch_bneck<16, CI, CM, CO, MREP, NW, YAMD_ACT_SILU>(p, batch, st)
                         : launch_bneck<20, CI, CM, CO, MREP, NW, YAMD_ACT_SILU>(p, batch, st);
+    if (p.act == YAMD_ACT_LEAKY)
+        return tw == 16 ? launch_bneck<16, CI, CM, CO, MREP, NW, YAMD_ACT_LEAKY>(p, batch, st)
+                        : launch_bneck<20, CI, CM, CO, MREP, NW, YAMD_ACT_LEAKY>(p, batch, st);
+    if (p.act == YAMD_ACT_MISH)
+        return tw == 16 ? launch_bneck<16, CI, CM, CO, MREP, NW, YAMD_ACT_MISH>(p, batch, st)
+                        : launch_bneck<20, CI, CM, CO, MREP, NW, YAMD_ACT_MISH>(p, batch, st);
     return tw == 16 ? launch_bneck<16, CI, CM, CO, MREP, NW, -1>(p, batch, st) : launch_bneck<20, CI, CM, CO, MREP, NW, -1>(p, batch, st);
 }
 
